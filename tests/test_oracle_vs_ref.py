@@ -1,0 +1,87 @@
+"""Pins the CPU oracle (oracle/lz4_oracle.c) against the reference's own C compiled in place
+(oracle/_ref/libref_lz4.so): byte-identical output and identical return codes for the fast encoder
+(both table variants), LZ4HC, and both decoders, including the limited-output / wrong-size /
+corrupted-stream matrix of original/fuzzer.c:176-227.  Skipped only where oracle/_ref is absent."""
+import numpy as np
+import pytest
+
+from oracle.oracle import compress_bound
+
+SIZES = (0, 1, 5, 12, 13, 14, 64, 255, 1000, 4096, 32768, 65535, 65536, 65546, 65547, 70000, 200000)
+
+
+def _inputs(oracle):
+    rng = np.random.default_rng(1)
+    for dist in range(4):
+        for seed in range(2):
+            for n in SIZES:
+                yield f"d{dist}s{seed}n{n}", oracle.gen(dist, seed, n, 1, max(n, 1))[0][:n]
+    for n in (100, 5000, 65536, 150000):
+        for k in (2, 3, 16):
+            yield f"alpha{k}n{n}", rng.integers(0, k, n, dtype=np.uint8)
+
+
+def test_encoders_identical(oracle, reference):
+    for name, a in _inputs(oracle):
+        bound = compress_bound(a.size)
+        for hc in (False, True):
+            r1, b1 = reference.compress_raw(a, bound, hc)
+            r2, b2 = oracle.compress_raw(a, bound, hc)
+            assert r1 == r2 and r1 > 0, (name, hc, r1, r2)
+            assert np.array_equal(b1[:r1], b2[:r2]), (name, hc)
+            assert (b2[bound:] == 0xA5).all(), (name, hc, "wrote past the bound")
+            for cap in (r1, r1 - 1, r1 // 2, 0, 1, 12):       # original/fuzzer.c:212-227
+                q1, _ = reference.compress_raw(a, cap, hc)
+                q2, x2 = oracle.compress_raw(a, cap, hc)
+                assert q1 == q2, (name, hc, cap, q1, q2)
+                if not hc:   # (the reference's HC emitter can overrun a too-small cap: lz4hc.c:541)
+                    assert (x2[max(cap, 0):] == 0xA5).all(), (name, cap, "canary")
+
+
+def test_decoders_identical(oracle, reference):
+    rng = np.random.default_rng(2)
+    for name, a in _inputs(oracle):
+        n = a.size
+        for hc in (False, True):
+            c = reference.compress(a, hc)
+            for osize in (n, n - 1, n + 1, n // 2):           # original/fuzzer.c:185-194
+                if osize < 0:
+                    continue
+                d1, o1 = reference.uncompress_raw(c, osize)
+                d2, o2 = oracle.uncompress_raw(c, osize)
+                assert d1 == d2, (name, hc, osize, d1, d2)
+                if d1 >= 0:
+                    assert np.array_equal(o1[:osize], o2[:osize])
+                assert (o2[osize:] == 0xA5).all()
+            r1 = len(c)
+            for isz, mo in ((r1, n), (r1, n + 1), (r1, n - 1), (r1 - 1, n), (r1 + 1, n), (r1, n + 100),
+                            (0, n), (r1, n // 2)):             # original/fuzzer.c:196-210
+                if mo < 0 or isz < 0:
+                    continue
+                d1, o1 = reference.uncompress_unknown_raw(c, isz, mo)
+                d2, o2 = oracle.uncompress_unknown_raw(c, isz, mo)
+                assert d1 == d2, (name, hc, isz, mo, d1, d2)
+                if d1 >= 0:
+                    assert np.array_equal(o1[:d1], o2[:d1])
+                assert (o2[mo:] == 0xA5).all()
+            if r1 > 20:                                        # corrupted streams: same error position
+                for _ in range(8):
+                    cc = c.copy()
+                    cc[rng.integers(0, r1)] = rng.integers(0, 256)
+                    assert reference.uncompress_raw(cc, n)[0] == oracle.uncompress_raw(cc, n)[0], name
+                    assert (reference.uncompress_unknown_raw(cc, r1, n)[0]
+                            == oracle.uncompress_unknown_raw(cc, r1, n)[0]), name
+
+
+def test_alignment_independence(oracle, reference):
+    # HC chain slots are address & 0xFFFF in the reference; for any block the result
+    # must not depend on where the buffer lives.  Place the same block at several offsets.
+    a = oracle.gen(2, 9, 0, 1, 65536)[0]
+    want = oracle.compress(a, hc=True)
+    import ctypes as C
+    big = np.zeros(65536 * 3 + 64, dtype=np.uint8)
+    for off in (0, 1, 7, 65535, 65536, 65537, 40000):
+        big[off:off + 65536] = a
+        out = np.zeros(compress_bound(65536), dtype=np.uint8)
+        ret = reference._hc(big.ctypes.data + off, out.ctypes.data, 65536, out.size)
+        assert ret == len(want) and np.array_equal(out[:ret], want), off
