@@ -1,0 +1,284 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: batched 64 KiB-block LZ4 decode on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--dist D] [--no-extras]
+
+One "step" = one pass of the batched known-size decoder over the whole resident batch (2^20 blocks of
+64 KiB per GPU by default; every buffer is in HBM before the timed region starts).  For N > 1 the driver
+launches one process per GPU (torch.distributed.run); blocks are sharded round-robin, there is no
+data-path collective, and the batch grows with N (weak scaling).
+
+Prints ONE JSON line (rank 0).  `value` = uncompressed GB/s of the decode step over all ranks;
+`roofline` = algorithmic bytes (u_i + c_i + 8 per block) / mean kernel time from HIP events on the
+launch stream vs the 8 TB/s HBM3E peak; `cpu_baseline` = the reference's own C (oracle/_ref, built
+from original/lz4.c) or, if absent, the CPU restatement, decoding a bounded sample of the same
+workload on this box's host cores.  `extras` carries the other distributions and the encoder rates.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+DIST_NAMES = {0: "D0-zeros", 1: "D1-incompressible", 2: "D2-fuzzer(original/fuzzer.c)", 3: "D3-records"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks PER GPU")
+    ap.add_argument("--dist", type=int, default=2, help="headline distribution (0..3)")
+    ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--hc-blocks", type=int, default=1 << 14, help="blocks for the LZ4HC extra (0 = skip)")
+    return ap.parse_args()
+
+
+def event_ms(fn, torch):
+    """Run fn() bracketed by HIP events on the current stream; returns elapsed ms (synchronises)."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b)
+
+
+class Workload:
+    """One distribution's device-resident batch: raw blocks, compressed blocks, lengths, decode target."""
+
+    def __init__(self, torch, batch, dist, seed, first_block, n, block_step=1):
+        self.torch, self.batch, self.dist, self.n = torch, batch, dist, n
+        self.raw = batch.synth(dist, seed, first_block, n, block_step=block_step)
+        self.comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+        self.clen = torch.empty(n, dtype=torch.int32, device="cuda")
+        self.back = torch.empty_like(self.raw)
+        self.used = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        # warm-up launch on a sliver (module load, LDS config), then the timed single-pass encode
+        batch.encode(self.raw[:64], batch.BLOCK, self.comp[:64], batch.BOUND, result=self.clen[:64])
+        torch.cuda.synchronize()
+        self.encode_ms = event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
+        self.comp_bytes = int(self.clen.to(torch.int64).sum().item())
+        assert bool((self.clen > 0).all()), "encoder reported failure on a block"
+
+    def decode_step(self):
+        self.batch.decode(self.comp, self.clen, self.back, self.batch.BLOCK, known_output_size=True, result=self.used)
+
+    def verify(self):
+        ok = bool((self.used == self.clen).all())
+        bad = self.batch.count_mismatches(self.raw, self.back, self.batch.BLOCK)
+        return ok and bad == 0
+
+    @property
+    def raw_bytes(self):
+        return self.n * self.batch.BLOCK
+
+    @property
+    def algorithmic_bytes(self):           # sum(u_i + c_i + 8)
+        return self.raw_bytes + self.comp_bytes + 8 * self.n
+
+
+def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
+    """The CPU codec on this box's host cores, bounded sample of the same workload (same generator,
+    same seed, first `sample_blocks` blocks).  Also the bench's parity spot check: the GPU's compressed
+    bytes for those blocks must equal the CPU reference's."""
+    import numpy as np
+    from oracle.oracle import Oracle, Reference
+    o = Oracle()
+    codec, kind = (Reference(), "reference") if Reference.available() else (o, "port")
+    cores = os.cpu_count() or 1
+    raw = o.gen(dist, seed, 0, sample_blocks)
+    bound = 65536 + 65536 // 255 + 16
+    comp = np.zeros((sample_blocks, bound), np.uint8)
+    lens = np.full(sample_blocks, 65536, np.int32)
+    caps = np.full(sample_blocks, bound, np.int32)
+    t_enc, clen = o.batch(codec, "enc", raw, lens, comp, caps, threads=cores)
+    parity = None
+    if gpu_comp_sample is not None:
+        g_comp, g_len = gpu_comp_sample
+        k = min(len(g_len), sample_blocks)
+        parity = bool((g_len[:k] == clen[:k]).all()) and all(
+            np.array_equal(g_comp[i, :clen[i]], comp[i, :clen[i]]) for i in range(k))
+    back = np.zeros_like(raw)
+    best = None
+    t0 = time.time()
+    passes = 0
+    while passes < 3 or (time.time() - t0 < 8.0 and passes < 50):
+        t, res = o.batch(codec, "dec", comp, clen, back, lens, threads=cores)
+        assert (res == clen).all()
+        best = t if best is None else min(best, t)
+        passes += 1
+    assert np.array_equal(back, raw)
+    return {
+        "value": round(sample_blocks * 65536 / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
+        "sample": f"{sample_blocks} x 64 KiB {DIST_NAMES[dist]} blocks (first blocks of the GPU batch), decode, "
+                  f"best of {passes} passes, {cores} threads; encode on the same sample "
+                  f"{round(sample_blocks * 65536 / t_enc / 1e9, 3)} GB/s",
+        "encode_value": round(sample_blocks * 65536 / t_enc / 1e9, 3),
+        "gpu_bytes_equal_cpu_reference": parity,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the codec")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from lz4net_amd import batch, _lib
+    _lib.lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- size the batch to the memory actually free on this GPU ------------------------------------
+    n = args.blocks
+    free, total = torch.cuda.mem_get_info()
+    per_block = 2 * batch.BLOCK + batch.BOUND_STRIDE + 16
+    while n * per_block * 1.03 > free and n > 1024:
+        n //= 2
+    # round-robin shard of a global batch of n*world blocks: local block j is global block j*world + rank
+    seed = args.seed
+    wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world)
+    for _ in range(max(args.warmup, 0)):
+        wl.decode_step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(event_ms(wl.decode_step, torch))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ok = wl.verify()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(wl.algorithmic_bytes), float(wl.comp_bytes), float(ok)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    all_ok = int(stats[2].item()) == world
+
+    # ---- extras: the other distributions (decode) and the encoders, rank 0 at N == 1 only -----------
+    extras = {}
+    gpu_sample = None
+    sample_blocks = min(2048, n)
+    if rank == 0:
+        k = min(64, n)
+        gpu_sample = (wl.comp[:k].cpu().numpy(), wl.clen[:k].cpu().numpy())
+    head = {
+        "decode_GBps": round(wl.raw_bytes / (sum(kernel_ms) / len(kernel_ms) / 1e3) / 1e9, 2),
+        "encode_fast_GBps": round(wl.raw_bytes / (wl.encode_ms / 1e3) / 1e9, 2),
+        "ratio": round(wl.comp_bytes / wl.raw_bytes, 4), "blocks": n, "roundtrip_ok": ok,
+    }
+    extras[DIST_NAMES[args.dist]] = head
+    alg_bytes_local, mean_kernel_ms = wl.algorithmic_bytes, sum(kernel_ms) / len(kernel_ms)
+    if world == 1 and not args.no_extras:
+        del wl
+        torch.cuda.empty_cache()
+        for d in range(4):
+            if d == args.dist:
+                continue
+            w = Workload(torch, batch, d, seed, 0, n)
+            w.decode_step()
+            torch.cuda.synchronize()
+            ms = [event_ms(w.decode_step, torch) for _ in range(3)]
+            extras[DIST_NAMES[d]] = {
+                "decode_GBps": round(w.raw_bytes / (min(ms) / 1e3) / 1e9, 2),
+                "decode_frac_of_hbm_peak": round(w.algorithmic_bytes / (min(ms) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                "encode_fast_GBps": round(w.raw_bytes / (w.encode_ms / 1e3) / 1e9, 2),
+                "ratio": round(w.comp_bytes / w.raw_bytes, 4), "blocks": n, "roundtrip_ok": w.verify(),
+            }
+            del w
+            torch.cuda.empty_cache()
+        if args.hc_blocks > 0:
+            m = min(args.hc_blocks, n)
+            raw = batch.synth(args.dist, seed, 0, m)
+            comp = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+            batch.encode(raw[:64], batch.BLOCK, comp[:64], batch.BOUND, hc=True)
+            torch.cuda.synchronize()
+            clen_holder = {}
+            ms = event_ms(lambda: clen_holder.setdefault("c", batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)), torch)
+            clen = clen_holder["c"]
+            back = torch.empty_like(raw)
+            used = batch.decode(comp, clen, back, batch.BLOCK)
+            extras["LZ4HC " + DIST_NAMES[args.dist]] = {
+                "encode_hc_GBps": round(m * batch.BLOCK / (ms / 1e3) / 1e9, 3),
+                "ratio": round(float(clen.double().sum().item()) / (m * batch.BLOCK), 4), "blocks": m,
+                "roundtrip_ok": bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0,
+            }
+            del raw, comp, back
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        try:
+            cpu = cpu_baseline(args.dist, seed, gpu_sample, sample_blocks)
+        except Exception as e:   # the bench line must still be printed
+            cpu = {"error": repr(e)}
+
+    total_raw = n * batch.BLOCK * world
+    ms_per_step = elapsed / args.steps * 1e3
+    achieved = alg_bytes_local / (mean_kernel_ms / 1e3) / 1e9
+    line = {
+        "metric": "uncompressed GB/s, batched 64KiB-block decode (known output size), per-step over the whole resident batch",
+        "value": round(total_raw / (elapsed / args.steps) / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: batched decode of {n} x 64 KiB pre-compressed blocks per GPU "
+                        f"({DIST_NAMES[args.dist]}, compressed on the GPU by the bit-exact fast encoder), known output size",
+            "blocks_per_gpu": n, "block_bytes": batch.BLOCK, "distribution": DIST_NAMES[args.dist],
+            "sharding": f"round-robin by rank, {world} rank(s), no data-path collective",
+            "frac_of_aggregate_hbm_peak": round(float(stats[0].item()) / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "lz4hip::decode_kernel<true>",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),
+        },
+        "cpu_baseline": cpu,
+        "verified": all_ok,
+        "extras": extras,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

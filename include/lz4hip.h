@@ -1,0 +1,105 @@
+/*
+ * lz4hip.h -- C ABI of liblz4hip.so: the MI355X (gfx950) batched LZ4 block codec that stands in for
+ * lz4net's back-end ladder (LZ4mm / LZ4cc / LZ4pn / LZ4ps) behind LZ4.LZ4Codec.Encode/Decode/EncodeHC.
+ *
+ * Plain C, plain pointers and sizes: P/Invoke-able from C# (bindings/csharp/HipLZ4Service.cs), callable
+ * through ctypes (lz4net_amd/_lib.py) and from C/C++ (include/lz4net/LZ4Codec.hpp).  All paths below
+ * citing the reference are relative to the lz4net repository.
+ *
+ * Conventions (identical to the reference's core functions):
+ *   encode           : bytes written, or 0 when the output limit would be exceeded
+ *   decode, known    : bytes CONSUMED from the source, or -(error position in the source)
+ *   decode, unknown  : bytes PRODUCED, or -(error position in the source)
+ * Library-level failures (no device, HIP error, bad argument) are reported as LZ4HIP_E_* values,
+ * which are far outside the range of any codec result, plus lz4hip_last_error().
+ * There is no CPU fallback: without a usable gfx950 device every call fails with LZ4HIP_E_DEVICE.
+ *
+ * Thread safety: all entry points are re-entrant.  Host-pointer calls use per-thread device scratch
+ * and the per-thread default stream; device-pointer calls are asynchronous on the stream given.
+ */
+#ifndef LZ4HIP_H
+#define LZ4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZ4HIP_E_DEVICE   (-2000000001)   /* no usable HIP device / HIP runtime error */
+#define LZ4HIP_E_ARGUMENT (-2000000002)   /* null pointer, negative size, ... */
+#define LZ4HIP_E_MEMORY   (-2000000003)   /* device allocation failed */
+
+#define LZ4HIP_MODE_FAST 0
+#define LZ4HIP_MODE_HC   1
+
+/* ---- information ------------------------------------------------------------------------------ */
+/* Counterpart of LZ4Codec.CodecName (src/LZ4/LZ4Codec.cs:298-308), e.g. "HIP gfx950 (AMD Instinct MI355X)". */
+const char* lz4hip_codec_name(void);
+int         lz4hip_device_count(void);
+const char* lz4hip_last_error(void);
+
+/* LZ4_compressBound (original/lz4.h:85-86) == LZ4Codec.MaximumOutputLength (src/LZ4ps/LZ4Codec.cs:142-145). */
+int lz4hip_compressBound(int isize);
+
+/* ---- single block, host memory, lz4.h-shaped ----------------------------------------------------
+ * Drop-in for the functions lz4net's native back-end binds (src/LZ4cc/LZ4Codec.64.cpp:31-36,81-100,
+ * 139-144 call I64_LZ4_compress_limitedOutput / I64_LZ4_uncompress / I64_LZ4_uncompress_unknownOutputSize /
+ * I64_LZ4_compressHC_limitedOutput; declarations original/lz4.h:59-60,101,116 and original/lz4hc.h:47,57). */
+int lz4hip_compress_limitedOutput(const char* source, char* dest, int isize, int maxOutputSize);
+int lz4hip_compress(const char* source, char* dest, int isize);
+int lz4hip_compressHC_limitedOutput(const char* source, char* dest, int isize, int maxOutputSize);
+int lz4hip_compressHC(const char* source, char* dest, int isize);
+int lz4hip_uncompress(const char* source, char* dest, int osize);
+int lz4hip_uncompress_unknownOutputSize(const char* source, char* dest, int isize, int maxOutputSize);
+/* Known-size decode that is also told the source length and never reads past it -- what
+ * ILZ4Service.Decode(..., knownOutputLength: true) needs (src/LZ4/ILZ4Service.cs:30-36: the service
+ * always has inputLength; the wrapper compares the result with it, src/LZ4pn/LZ4Codec.Unsafe.cs:373-378). */
+int lz4hip_uncompress_bounded(const char* source, int isize, char* dest, int osize);
+
+/* ---- batches -------------------------------------------------------------------------------------
+ * The reference has no batch API; lz4net users loop over LZ4Codec.Encode/Decode per block (e.g.
+ * LZ4Stream.FlushCurrentChunk / AcquireNextChunk, src/LZ4/LZ4Stream.cs:239-312).  One descriptor
+ * describes n independent blocks; block i starts at base + (off ? off[i] : i * stride). */
+typedef struct lz4hip_batch {
+    const void*    src;
+    const int64_t* src_off;      /* optional byte offsets (packed layouts), else NULL */
+    int64_t        src_stride;
+    const int32_t* src_len;      /* per-block input bytes, or NULL to use src_len_all */
+    void*          dst;
+    const int64_t* dst_off;
+    int64_t        dst_stride;
+    const int32_t* dst_cap;      /* per-block capacity (encode, unknown-size decode) or exact size (known-size decode); NULL => dst_cap_all */
+    int32_t        dst_cap_all;
+    int32_t        src_len_all;  /* length of every block when src_len == NULL; otherwise an optional upper bound on src_len[i] (0 = unknown) */
+    int32_t*       result;       /* per-block codec result, conventions above */
+    int64_t        n_blocks;
+} lz4hip_batch_t;
+
+/* Device-resident batches: every pointer in *b is device memory of the CURRENT device; the call only
+ * enqueues kernels on `stream` (a hipStream_t, NULL = default stream) and returns 0 or LZ4HIP_E_*. */
+int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream);
+int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream);
+
+/* Host-resident batches: stages through device memory (H2D, kernels, D2H) and synchronises. */
+int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode);
+int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
+
+/* ---- device-side synthetic data + verification (bench / tests) ---------------------
+ * dist: 0 zeros, 1 incompressible, 2 reference fuzzer generator (original/fuzzer.c:149-168), 3 record-like.
+ * Row i of `out` is synthetic block number first_block + i * block_step (block_step = world size gives a
+ * rank its round-robin share of a global batch).  Bit-identical to the CPU twins in oracle/synth.c. */
+int lz4hip_synth_device(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n_blocks,
+                        void* out, int64_t stride, int32_t len, void* stream);
+int lz4hip_checksum_device(const void* data, const int64_t* off, int64_t stride, const int32_t* len,
+                           int32_t len_all, uint64_t* sums, int64_t n_blocks, void* stream);
+/* *mismatches (device, unsigned 64-bit, caller zeroes it) += number of differing bytes */
+int lz4hip_compare_device(const void* a, int64_t a_stride, const void* b, int64_t b_stride,
+                          const int32_t* len, int32_t len_all, int64_t n_blocks, uint64_t* mismatches,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ4HIP_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of liblz4hip.so (the C ABI of include/lz4hip.h).
+
+There is no fallback of any kind: if the shared library is missing it is built with hipcc, and if that
+is impossible the import fails loudly.  Calls on a machine without a gfx950 device return
+LZ4HIP_E_DEVICE, which the wrappers turn into Lz4HipError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import build as _build
+
+E_DEVICE, E_ARGUMENT, E_MEMORY = -2000000001, -2000000002, -2000000003
+MODE_FAST, MODE_HC = 0, 1
+
+
+class Lz4HipError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    """struct lz4hip_batch (include/lz4hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("src_off", C.c_void_p), ("src_stride", C.c_int64), ("src_len", C.c_void_p),
+                ("dst", C.c_void_p), ("dst_off", C.c_void_p), ("dst_stride", C.c_int64), ("dst_cap", C.c_void_p),
+                ("dst_cap_all", C.c_int32), ("src_len_all", C.c_int32), ("result", C.c_void_p),
+                ("n_blocks", C.c_int64)]
+
+
+# every symbol include/lz4hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("lz4hip_codec_name", C.c_char_p, []),
+    ("lz4hip_device_count", C.c_int, []),
+    ("lz4hip_last_error", C.c_char_p, []),
+    ("lz4hip_compressBound", C.c_int, [C.c_int]),
+    ("lz4hip_compress_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("lz4hip_compress", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("lz4hip_compressHC_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("lz4hip_compressHC", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("lz4hip_uncompress", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("lz4hip_uncompress_unknownOutputSize", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("lz4hip_uncompress_bounded", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    ("lz4hip_encode_batch_device", C.c_int, [C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("lz4hip_decode_batch_device", C.c_int, [C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("lz4hip_encode_batch_host", C.c_int, [C.POINTER(Batch), C.c_int]),
+    ("lz4hip_decode_batch_host", C.c_int, [C.POINTER(Batch), C.c_int]),
+    ("lz4hip_synth_device", C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    ("lz4hip_checksum_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("lz4hip_compare_device", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = _build.build()                     # raises if the library cannot be produced
+        handle = C.CDLL(so)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(handle, name)          # AttributeError == ABI drift: fail loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> int:
+    """Raise on library-level failures (LZ4HIP_E_*); pass codec results through."""
+    if rc <= E_DEVICE and rc >= E_MEMORY:
+        raise Lz4HipError(f"liblz4hip error {rc}: {lib().lz4hip_last_error().decode(errors='replace')}")
+    return rc

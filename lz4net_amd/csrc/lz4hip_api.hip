@@ -1,0 +1,379 @@
+// lz4hip_api.hip -- host side of liblz4hip.so: the C ABI declared in include/lz4hip.h.
+//
+// Only launches the gfx950 kernels of this directory; there is deliberately NO CPU code path for
+// the codec here (a missing/unsupported device is an error, never a fallback).
+#include "lz4hip_wave.hpp"
+
+#include "lz4hip_common.hpp"
+#include "lz4hip_decode.hpp"
+#include "lz4hip_encode.hpp"
+#include "lz4hip_hc.hpp"
+#include "lz4hip_synth.hpp"
+
+#include "../../include/lz4hip.h"
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace lz4hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& what)
+{
+    g_last_error = what;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? LZ4HIP_E_MEMORY : LZ4HIP_E_DEVICE,          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+// The library refuses to run anywhere but on the architecture its kernels were written for.
+int ensure_device()
+{
+    static thread_local int checked_device = -1;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(LZ4HIP_E_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (dev == checked_device) return 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(LZ4HIP_E_DEVICE, std::string("liblz4hip is built for gfx950 only, device is ") + prop.gcnArchName);
+    checked_device = dev;
+    return 0;
+}
+
+Batch to_device_batch(const lz4hip_batch_t& b)
+{
+    Batch d;
+    d.src = (const uint8_t*)b.src; d.src_off = b.src_off; d.src_stride = b.src_stride; d.src_len = b.src_len;
+    d.dst = (uint8_t*)b.dst; d.dst_off = b.dst_off; d.dst_stride = b.dst_stride; d.dst_cap = b.dst_cap;
+    d.dst_cap_all = b.dst_cap_all; d.src_len_all = b.src_len_all; d.result = b.result; d.n_blocks = b.n_blocks;
+    return d;
+}
+
+int check_batch(const lz4hip_batch_t* b)
+{
+    if (!b) return fail(LZ4HIP_E_ARGUMENT, "batch descriptor is NULL");
+    if (b->n_blocks < 0) return fail(LZ4HIP_E_ARGUMENT, "n_blocks < 0");
+    if (b->n_blocks > 0 && (!b->src || !b->dst || !b->result))
+        return fail(LZ4HIP_E_ARGUMENT, "src, dst and result must be non-NULL");
+    if (b->n_blocks > 0x7FFFFFFF) return fail(LZ4HIP_E_ARGUMENT, "n_blocks too large for one launch");
+    return 0;
+}
+
+// ---- grow-only per-thread device scratch for the host-pointer entry points --------------------
+struct Scratch {
+    void* p = nullptr; size_t cap = 0; int dev = -1;
+    int reserve(size_t n)
+    {
+        int dev_now = 0;
+        HIP_TRY(hipGetDevice(&dev_now));
+        if (p && (dev_now != dev || n > cap)) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (!p) {
+            size_t want = n < (1u << 20) ? (1u << 20) : n;
+            HIP_TRY(hipMalloc(&p, want));
+            cap = want; dev = dev_now;
+        }
+        return 0;
+    }
+    ~Scratch() { /* the HIP runtime may already be gone at thread exit: leak on purpose */ }
+};
+thread_local Scratch g_scratch;
+
+// HC chain tables: 128 KiB of global scratch per resident workgroup (see lz4hip_hc.hpp)
+struct HcWorkspace {
+    void* p = nullptr; size_t cap = 0; int dev = -1;
+    std::mutex mu;
+};
+HcWorkspace g_hc_ws[64];
+
+int hc_workspace(size_t bytes, void** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+    HcWorkspace& w = g_hc_ws[dev];
+    std::lock_guard<std::mutex> lock(w.mu);
+    if (w.cap < bytes) {
+        if (w.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
+        HIP_TRY(hipMalloc(&w.p, bytes));
+        w.cap = bytes;
+    }
+    *out = w.p;
+    return 0;
+}
+
+int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
+{
+    if (b->n_blocks == 0) return 0;
+    const Batch d = to_device_batch(*b);
+    if (mode == LZ4HIP_MODE_FAST) {
+        hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d);
+    } else if (mode == LZ4HIP_MODE_HC) {
+        int dev = 0, cus = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        // 16-bit heads (64 KiB of LDS, two workgroups per CU) when every block is known to be <= 64 KiB:
+        // uniform length, or per-block lengths with src_len_all carrying an upper bound (0 = unknown).
+        const bool small = b->src_len_all > 0 && b->src_len_all <= 65536;
+        const int lds_bytes = small ? kHcLdsHeads16 : kHcLdsHeads32;
+        int64_t groups = (int64_t)cus * (small ? kHcGroupsPerCu : 1);
+        if (groups > d.n_blocks) groups = d.n_blocks;
+        void* ws = nullptr;
+        int rc = hc_workspace((size_t)groups * kHcGlobalBytesPerGroup + 256, &ws);
+        if (rc) return rc;
+        // first 8 bytes of the workspace: the work counter of the persistent grid
+        HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+        if (!small) HIP_TRY(hipFuncSetAttribute((const void*)encode_hc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(encode_hc_kernel, dim3((unsigned)groups), dim3(64), lds_bytes, stream, d,
+                           (unsigned long long*)ws, (uint8_t*)ws + 256, lds_bytes);
+    } else {
+        return fail(LZ4HIP_E_ARGUMENT, "mode must be LZ4HIP_MODE_FAST or LZ4HIP_MODE_HC");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
+{
+    if (b->n_blocks == 0) return 0;
+    const Batch d = to_device_batch(*b);
+    const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
+    if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d);
+    else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
+template <class Run>
+int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
+{
+    int rc = check_batch(hb);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    const int64_t n = hb->n_blocks;
+    if (n == 0) return 0;
+
+    // tight device layout: per-block slots of the maximum length, 16-byte aligned
+    int64_t max_src = 0, max_dst = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t sl = hb->src_len ? hb->src_len[i] : hb->src_len_all;
+        const int32_t dc = hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all;
+        if (sl < 0) return fail(LZ4HIP_E_ARGUMENT, "negative source length");
+        max_src = sl > max_src ? sl : max_src;
+        max_dst = dc > max_dst ? dc : max_dst;
+    }
+    const size_t s_stride = align_up((size_t)max_src + 16, 16), d_stride = align_up((size_t)max_dst + 16, 16);
+    const size_t o_src = 0, o_dst = align_up(o_src + s_stride * (size_t)n, 256),
+                 o_sl = align_up(o_dst + d_stride * (size_t)n, 256), o_dc = o_sl + align_up(4 * (size_t)n, 256),
+                 o_res = o_dc + align_up(4 * (size_t)n, 256), total = o_res + align_up(4 * (size_t)n, 256);
+    if ((rc = g_scratch.reserve(total))) return rc;
+    uint8_t* base = (uint8_t*)g_scratch.p;
+    hipStream_t stream = hipStreamPerThread;
+
+    std::vector<int32_t> sl((size_t)n), dc((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        sl[(size_t)i] = hb->src_len ? hb->src_len[i] : hb->src_len_all;
+        dc[(size_t)i] = hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all;
+        const uint8_t* s = (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride);
+        if (sl[(size_t)i] > 0)
+            HIP_TRY(hipMemcpyAsync(base + o_src + s_stride * (size_t)i, s, (size_t)sl[(size_t)i], hipMemcpyHostToDevice, stream));
+    }
+    HIP_TRY(hipMemcpyAsync(base + o_sl, sl.data(), 4 * (size_t)n, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(base + o_dc, dc.data(), 4 * (size_t)n, hipMemcpyHostToDevice, stream));
+
+    lz4hip_batch_t db;
+    db.src = base + o_src; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(base + o_sl);
+    db.dst = base + o_dst; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(base + o_dc);
+    db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(base + o_res); db.n_blocks = n;
+    if ((rc = run(&db, stream))) return rc;
+
+    HIP_TRY(hipMemcpyAsync(hb->result, base + o_res, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int64_t i = 0; i < n; i++) {
+        // bytes the caller gets back: the result for encoders / unknown-size decode, the full size for known-size decode
+        int64_t nbytes = dst_len_is_result ? hb->result[i] : dc[(size_t)i];
+        if (!dst_len_is_result && hb->result[i] < 0) nbytes = 0;
+        if (nbytes <= 0) continue;
+        if (nbytes > dc[(size_t)i]) nbytes = dc[(size_t)i];
+        uint8_t* d = (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride);
+        HIP_TRY(hipMemcpyAsync(d, base + o_dst + d_stride * (size_t)i, (size_t)nbytes, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int single(const char* src, int src_len, char* dst, int dst_cap, int kind /*0 fast,1 hc,2 dec known,3 dec unknown*/)
+{
+    if (!src || !dst) return fail(LZ4HIP_E_ARGUMENT, "NULL buffer");
+    if (src_len < 0) return fail(LZ4HIP_E_ARGUMENT, "negative length");
+    int32_t result = 0;
+    lz4hip_batch_t b;
+    b.src = src; b.src_off = nullptr; b.src_stride = 0; b.src_len = nullptr; b.src_len_all = src_len;
+    b.dst = dst; b.dst_off = nullptr; b.dst_stride = 0; b.dst_cap = nullptr; b.dst_cap_all = dst_cap < 0 ? 0 : dst_cap;
+    b.result = &result; b.n_blocks = 1;
+    int rc = kind <= 1 ? lz4hip_encode_batch_host(&b, kind) : lz4hip_decode_batch_host(&b, kind == 2);
+    return rc ? rc : result;
+}
+
+// Number of source bytes a known-size decode of `osize` output bytes will look at.  This only walks
+// the token / length bytes (no byte of payload is decoded on the host): LZ4_uncompress() is not
+// told its input size (original/lz4.c:812-814), so the extent of the H2D copy has to come from the
+// stream itself.  Mirrors the control flow of lz4hip::decode_block<true>.
+int known_size_extent(const uint8_t* src, int osize)
+{
+    int64_t ip = 0, op = 0;
+    for (;;) {
+        unsigned token = src[ip++];
+        int64_t ll = token >> 4;
+        if (ll == 15) { unsigned b; do { b = src[ip++]; ll += b; } while (b == 255 && ll < (1 << 30)); }
+        if (op + ll > (int64_t)osize - 8) return (int)(op + ll == osize ? ip + ll : ip);
+        ip += ll; op += ll;
+        ip += 2;
+        int64_t ml = token & 15;
+        if (ml == 15) { while (src[ip] == 255 && ml < (1 << 30)) { ml += 255; ip++; } ml += src[ip++]; }
+        op += ml + 4;
+        if (op > (int64_t)osize - 5) return (int)ip;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lz4hip_last_error(void) { return g_last_error.c_str(); }
+
+int lz4hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* lz4hip_codec_name(void)
+{
+    static thread_local std::string name;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        name = "HIP gfx950 (no device)";
+    } else {
+        name = std::string("HIP ") + prop.gcnArchName + " (" + prop.name + ")";
+    }
+    return name.c_str();
+}
+
+int lz4hip_compressBound(int isize) { return isize + isize / 255 + 16; }
+
+int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream)
+{
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    return launch_encode(b, mode, (hipStream_t)stream);
+}
+
+int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream)
+{
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    return launch_decode(b, known_output_size, (hipStream_t)stream);
+}
+
+int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode)
+{
+    return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); });
+}
+
+int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
+{
+    return run_host_batch(b, !known_output_size,
+                          [known_output_size](const lz4hip_batch_t* db, hipStream_t s) { return launch_decode(db, known_output_size, s); });
+}
+
+int lz4hip_compress_limitedOutput(const char* source, char* dest, int isize, int maxOutputSize)
+{
+    return single(source, isize, dest, maxOutputSize, 0);
+}
+int lz4hip_compress(const char* source, char* dest, int isize)
+{
+    return single(source, isize, dest, lz4hip_compressBound(isize), 0);
+}
+int lz4hip_compressHC_limitedOutput(const char* source, char* dest, int isize, int maxOutputSize)
+{
+    return single(source, isize, dest, maxOutputSize, 1);
+}
+int lz4hip_compressHC(const char* source, char* dest, int isize)
+{
+    return single(source, isize, dest, lz4hip_compressBound(isize) + 1, 1);   /* original/lz4hc.c:762 */
+}
+int lz4hip_uncompress_bounded(const char* source, int isize, char* dest, int osize)
+{
+    return single(source, isize, dest, osize, 2);
+}
+int lz4hip_uncompress(const char* source, char* dest, int osize)
+{
+    if (!source || !dest) return fail(LZ4HIP_E_ARGUMENT, "NULL buffer");
+    if (osize < 0) return fail(LZ4HIP_E_ARGUMENT, "negative length");
+    return single(source, known_size_extent((const uint8_t*)source, osize), dest, osize, 2);
+}
+int lz4hip_uncompress_unknownOutputSize(const char* source, char* dest, int isize, int maxOutputSize)
+{
+    return single(source, isize, dest, maxOutputSize, 3);
+}
+
+int lz4hip_synth_device(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n_blocks, void* out,
+                        int64_t stride, int32_t len, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_blocks <= 0 || len <= 0) return 0;
+    if (!out || dist < 0 || dist > 3) return fail(LZ4HIP_E_ARGUMENT, "bad synth arguments");
+    SynthArgs a = { (uint8_t*)out, stride, n_blocks, seed, first_block, block_step, len, dist };
+    const unsigned grid = dist <= 1 ? 16384u : (unsigned)((n_blocks + 63) / 64);
+    hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lz4hip_checksum_device(const void* data, const int64_t* off, int64_t stride, const int32_t* len,
+                           int32_t len_all, uint64_t* sums, int64_t n_blocks, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_blocks <= 0) return 0;
+    ChecksumArgs a = { (const uint8_t*)data, off, stride, len, len_all, sums, n_blocks };
+    hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lz4hip_compare_device(const void* a, int64_t a_stride, const void* b, int64_t b_stride,
+                          const int32_t* len, int32_t len_all, int64_t n_blocks, uint64_t* mismatches,
+                          void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_blocks <= 0) return 0;
+    CompareArgs c = { (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, len, len_all, n_blocks,
+                      (unsigned long long*)mismatches };
+    hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

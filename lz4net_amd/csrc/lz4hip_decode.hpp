@@ -1,0 +1,206 @@
+// lz4hip_decode.hpp -- batched LZ4 block decoders for gfx950, one wavefront per block.
+//
+// Replaces LZ4_uncompress (original/lz4.c:812-914 == LZ4_uncompress_64,
+// src/LZ4pn/LZ4Codec.Unsafe64.Dirty.cs:534-661) and LZ4_uncompress_unknownOutputSize
+// (original/lz4.c:916-1044 == src/LZ4pn/LZ4Codec.Unsafe64.Dirty.cs:667-806).
+//
+// Design (not a translation of the CPU copy loop):
+//  * the sequence parse is wave-uniform and lives in SGPRs.  The compressed stream is held in a
+//    512-byte register window (two dwords per lane, coalesced refills); token / length / offset
+//    bytes are extracted with v_readlane, so the parse never waits on memory;
+//  * a "short" sequence (literals + match <= 64 bytes) is materialised by ONE byte-per-lane store:
+//    literal bytes come out of the register window via ds_bpermute, match bytes are gathered from
+//    the already written output (global memory, L1/L2 resident) with the reference's byte-wise
+//    overlap semantics out[i] = out[i - offset] expressed as a modulo on the lane index;
+//  * long literal runs move 1 KiB per wave-instruction (16 B per lane);
+//  * long matches use the periodicity of an overlapping LZ77 copy: once `offset` bytes exist, the
+//    data is periodic, so the copy distance can be doubled every pass until it reaches 1 KiB and
+//    the remainder streams at 16 B per lane even for offset 1 (e.g. an all-zero block).
+//  Output is written straight to HBM (the 64 KiB window of a block is its own output, served from
+//  L2); no LDS is used, so residency is bounded by registers only (8 waves per SIMD).
+//
+// Return values are the reference's: known-size decode returns the number of source bytes consumed
+// or -(position of the error in the source); unknown-size decode returns bytes produced or
+// -(position).  The only deliberate difference: the known-size decoder is also given the source
+// length and never reads past it (the reference has undefined behaviour there); bytes past the end
+// parse as zero and a literal run that would cross the end is reported as an error at its position.
+#pragma once
+#include "lz4hip_common.hpp"
+
+namespace lz4hip {
+
+// 512-byte sliding register window over the compressed stream of one block.
+struct SrcWindow {
+    const uint8_t* src;
+    int len;        // bytes that may be read
+    int base;       // window covers [base, base + 512), base % 256 == 0
+    uint32_t w0, w1;
+
+    LZ4HIP_DEVICE uint32_t fetch(int off) const
+    {
+        uint32_t v = 0;
+        if (off + 4 <= len) {
+            v = load_u32(src + off);
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (off + k < len) v |= (uint32_t)src[off + k] << (8 * k);
+        }
+        return v;
+    }
+    LZ4HIP_DEVICE void init(const uint8_t* s, int n)
+    {
+        src = s; len = n; base = 0;
+        const int o = wv::lane() * 4;
+        w0 = fetch(o);
+        w1 = fetch(256 + o);
+    }
+    // make [p, p + n) addressable, n <= 256
+    LZ4HIP_DEVICE void need(int p, int n)
+    {
+        if (p + n > base + 512) {
+            const int nb = p & ~255;
+            const int o = wv::lane() * 4;
+            w0 = (nb == base + 256) ? w1 : fetch(nb + o);
+            w1 = fetch(nb + 256 + o);
+            base = nb;
+        }
+    }
+    // wave-uniform byte at wave-uniform position p
+    LZ4HIP_DEVICE uint32_t peek(int p)
+    {
+        need(p, 1);
+        const int idx = p - base, l = idx >> 2;
+        const uint32_t a = wv::readlane(w0, l & 63), b = wv::readlane(w1, l & 63);
+        return (((l & 64) ? b : a) >> ((idx & 3) * 8)) & 255u;
+    }
+    // per-lane byte at per-lane position p (caller guarantees p inside the window)
+    LZ4HIP_DEVICE uint32_t gather(int p) const
+    {
+        const int idx = p - base, l = idx >> 2;
+        const uint32_t a = wv::shuffle(w0, l & 63), b = wv::shuffle(w1, l & 63);
+        return (((l & 64) ? b : a) >> ((idx & 3) * 8)) & 255u;
+    }
+};
+
+// Overlapped LZ77 copy dst[pos + i] = dst[pos - off + i], i < n, off >= 1, by distance doubling.
+// Every pass only reads bytes that earlier passes (or earlier sequences) have already written.
+LZ4HIP_DEVICE void wave_match_copy(uint8_t* dst, int pos, int off, int n)
+{
+    const int lane = wv::lane();
+    int dist = off;                    // always a multiple of off, <= bytes available behind `cur`
+    int cur = pos, left = n;
+    while (left > 0) {
+        int step = left < dist ? left : dist;
+        if (step > 1024) step = 1024;
+        const uint8_t* from = dst + cur - dist;
+        uint8_t* to = dst + cur;
+        const int body = step & ~15;
+        if (lane * 16 < body) store_v16(to + lane * 16, load_v16(from + lane * 16));
+        const int t = body + lane;
+        if (t < step) to[t] = from[t];
+        wv::mem_sync();
+        if (step == dist && dist < 1024) dist += dist;
+        cur += step; left -= step;
+    }
+}
+
+template <bool KNOWN>
+LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, int out_size)
+{
+    const int lane = wv::lane();
+    const int iend = src_len, oend = out_size;
+    int ip = 0, op = 0;
+
+    if (!KNOWN && iend == 0) return 0;                      // original/lz4.c:946 returns -(0)
+    SrcWindow win;
+    win.init(src, src_len);
+
+    for (;;) {
+        // ---- token + literal length: lz4.c:843-844 / :953-961 ----
+        const uint32_t token = win.peek(ip); ip++;
+        int ll = (int)(token >> 4);
+        if (ll == 15) {
+            uint32_t b = 255;
+            if (KNOWN) { do { b = win.peek(ip); ip++; ll += (int)b; if (ll > (1 << 30)) return -ip; } while (b == 255); }
+            else       { while (ip < iend && b == 255) { b = win.peek(ip); ip++; ll += (int)b; } }
+        }
+        const int lit_end = op + ll;
+
+        // ---- last sequence (literals only): lz4.c:851-858 / :965-975 ----
+        const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || ip + ll > iend - 8);
+        if (last) {
+            if (KNOWN) { if (lit_end != oend) return -ip; if (ip + ll > iend) return -ip; }
+            else       { if (lit_end > oend) return -ip; if (ip + ll != iend) return -ip; }
+            wave_copy(dst + op, src + ip, ll);
+            return KNOWN ? ip + ll : lit_end;
+        }
+        if (KNOWN && ip + ll > iend) return -ip;           // never read literals past the source
+
+        // ---- literal bytes of a short run, taken from the register window before it slides ----
+        const bool short_lit = ll <= 64;
+        uint32_t lit_byte = 0;
+        if (short_lit && ll > 0) {
+            win.need(ip, 66);
+            lit_byte = win.gather(ip + (lane < ll ? lane : 0));
+        }
+
+        // ---- offset + match length: lz4.c:862-866 / :979-997 ----
+        int p = ip + ll;
+        const int off = (int)(win.peek(p) | (win.peek(p + 1) << 8));
+        p += 2;
+        const int ref = lit_end - off;
+        if (ref < 0) return -p;
+        int ml = (int)(token & 15);
+        if (ml == 15) {
+            if (KNOWN) {
+                uint32_t b;
+                while ((b = win.peek(p)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
+                ml += (int)b; p++;
+            } else {
+                while (p < iend - (kLastLiterals + 1)) { const uint32_t b = win.peek(p); p++; ml += (int)b; if (b != 255) break; }
+            }
+        }
+        ml += kMinMatch;
+        const int match_end = lit_end + ml;
+        if (match_end > oend - kLastLiterals) return -p;    // lz4.c:893 / :1024
+
+        // ---- materialise the sequence ----
+        if (short_lit && ll + ml <= 64) {
+            const int j = lane - ll;                         // index inside the match (valid when 0 <= j < ml)
+            const bool in_match = j >= 0 && j < ml && off != 0;
+            int jj = j < 0 ? 0 : j;
+            if (off < ml && off != 0) jj = jj % off;        // byte-wise overlap semantics
+            const int sidx = ref + jj;                       // source index in dst
+            const int from_lit = sidx - op;                  // >= 0: the byte is one of THIS sequence's literals
+            const uint32_t via_lit = wv::shuffle(lit_byte, from_lit < 0 ? 0 : from_lit);
+            uint32_t v = lit_byte;
+            if (in_match) v = from_lit >= 0 ? via_lit : (uint32_t)dst[sidx];
+            if (lane < ll || in_match) dst[op + lane] = (uint8_t)v;
+        } else {
+            if (ll > 0) {
+                if (short_lit) { if (lane < ll) dst[op + lane] = (uint8_t)lit_byte; }
+                else wave_copy(dst + op, src + ip, ll);
+                wv::mem_sync();
+            }
+            if (off != 0) wave_match_copy(dst, lit_end, off, ml);
+        }
+        wv::mem_sync();
+        ip = p; op = match_end;
+    }
+}
+
+// grid: ceil(n_blocks / waves_per_group) workgroups of 64 * waves_per_group threads.
+template <bool KNOWN>
+__global__ void __launch_bounds__(256) decode_kernel(Batch b)
+{
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv::wave_in_block();
+    if (blk >= b.n_blocks) return;
+    const int src_len = wv::uniform(batch_src_len(b, blk));
+    const int out_size = wv::uniform(batch_dst_cap(b, blk));
+    const uint8_t* src = batch_src(b, blk);
+    uint8_t* dst = batch_dst(b, blk);
+    const int r = decode_block<KNOWN>(src, src_len, dst, out_size);
+    if (wv::lane() == 0) b.result[blk] = r;
+}
+
+}  // namespace lz4hip

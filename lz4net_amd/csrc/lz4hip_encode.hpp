@@ -1,0 +1,211 @@
+// lz4hip_encode.hpp -- batched LZ4 fast block encoder for gfx950, one wavefront per block,
+// bit-exact to the reference.
+//
+// Replaces LZ4_compress64kCtx (original/lz4.c:573-771 == LZ4_compress64kCtx_64,
+// src/LZ4pn/LZ4Codec.Unsafe64.Dirty.cs:303-528) for inputs below LZ4_64KLIMIT and LZ4_compressCtx
+// (original/lz4.c:345-562 == LZ4_compressCtx_64, :75-297) above it, behind the dispatcher
+// LZ4_compress_limitedOutput (original/lz4.c:774-792 == Encode64, src/LZ4pn/LZ4Codec.Unsafe.cs:275-297).
+//
+// The greedy parse is a chain of hash-table read-modify-writes whose state depends on every
+// position visited, so (to stay bit-exact) its control state is wave-uniform: the 16 KiB hash
+// table lives in LDS (8192 x u16 / 4096 x u32, zero-filled per block exactly like the reference's
+// per-call table), the probe sequence runs on scalars, and the 64 lanes do the data-parallel parts:
+// backward catch-up and forward match counting by ballot + count-trailing-zeros over 4 bytes per
+// lane (256 bytes per step), literal copies at 16 B per lane, and length-byte fills.
+#pragma once
+#include "lz4hip_common.hpp"
+
+namespace lz4hip {
+
+template <bool GENERIC> struct FastTable;
+template <> struct FastTable<false> {   // 64k variant: U16 HashTable[8192], hash shift 19 (lz4.c:567-570,583)
+    typedef uint16_t entry;
+    static LZ4HIP_DEVICE uint32_t hash(uint32_t word) { return (word * kGolden) >> 19; }
+};
+template <> struct FastTable<true> {    // generic variant: U32 HashTable[4096], hash shift 20 (lz4.c:183-185,248)
+    typedef uint32_t entry;
+    static LZ4HIP_DEVICE uint32_t hash(uint32_t word) { return (word * kGolden) >> 20; }
+};
+
+// wave-uniform unaligned dword of the input at wave-uniform position p
+LZ4HIP_DEVICE uint32_t input_word(const uint8_t* in, int p) { return wv::uniform(load_u32(in + p)); }
+
+// Number of equal bytes in[a + i] == in[b + i] for i < limit - a (a > b), counted 4 bytes per lane.
+// Equals the reference's 8-byte XOR/ctz loop plus its 4/2/1-byte tails (lz4.c:698-721).
+LZ4HIP_DEVICE int wave_common_length(const uint8_t* in, int a, int b, int limit)
+{
+    const int lane = wv::lane();
+    int total = 0;
+    for (;;) {
+        const int pa = a + total + lane * 4;
+        int valid = limit - pa;                       // bytes of this lane's dword that may be counted
+        valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
+        uint32_t diff = 1;                            // valid == 0: "differs at byte 0"
+        if (valid > 0) {
+            diff = load_u32(in + pa) ^ load_u32(in + b + total + lane * 4);
+            if (valid < 4) diff |= 1u << (8 * valid); // sentinel at the first byte that must not count
+        }
+        const uint64_t stop = wv::ballot(diff != 0);
+        if (stop) {
+            const int first = wv::ctz64(stop);
+            const uint32_t d = wv::readlane(diff, first);
+            return total + first * 4 + (__builtin_ctz(d) >> 3);
+        }
+        total += 256;
+    }
+}
+
+// Number of bytes the match can be extended backwards: in[ip-1-i] == in[ref-1-i], i < bound.
+LZ4HIP_DEVICE int wave_catch_up(const uint8_t* in, int ip, int ref, int bound)
+{
+    const int lane = wv::lane();
+    int total = 0;
+    while (total < bound) {
+        const int i = total + lane;
+        const bool differs = i >= bound || in[ip - 1 - i] != in[ref - 1 - i];
+        const uint64_t stop = wv::ballot(differs);
+        if (stop) return total + wv::ctz64(stop);
+        total += 64;
+    }
+    return bound;
+}
+
+// length bytes for a literal-run / match length whose nibble saturated: `rest` = length - 15
+// -> floor(rest / 255) bytes of 255, then rest % 255.  Returns bytes written.
+LZ4HIP_DEVICE int put_length_bytes(uint8_t* out, int rest)
+{
+    const int n255 = rest / 255;
+    wave_fill(out, 255, n255);
+    if (wv::lane() == 0) out[n255] = (uint8_t)(rest - n255 * 255);
+    return n255 + 1;
+}
+
+template <bool GENERIC>
+LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int cap, unsigned char* table_bytes)
+{
+    typedef FastTable<GENERIC> T;
+    typedef typename T::entry entry;
+    entry* table = (entry*)table_bytes;
+    const int lane = wv::lane();
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    int ip = 0, anchor = 0, op = 0;
+
+    if (n >= kMinLength) {                                            // lz4.c:615
+        // fresh zeroed table per block (lz4.c:583 / `new ushort[8192]`, Unsafe.cs:283)
+        for (int k = lane * 16; k < kFastTableBytes; k += 64 * 16) {
+            Vec16 z = { { 0, 0, 0, 0 } };
+            *(Vec16*)(table_bytes + k) = z;
+        }
+        wv::mem_sync();
+
+        if (GENERIC) {                                                // lz4.c:403: position 0 is inserted
+            const uint32_t h0 = T::hash(input_word(in, 0));           // (a no-op on a zeroed table; kept for clarity)
+            if (lane == 0) table[h0] = 0;
+        }
+        ip = 1;                                                       // lz4.c:631: position 0 is never probed
+        uint32_t fwd_word = input_word(in, ip);
+        for (;;) {
+            // ---- find a match: lz4.c:642-654 ----
+            int attempts = 67, probe = ip, ref;
+            uint32_t cur_word;
+            bool out_of_input = false;
+            for (;;) {
+                cur_word = fwd_word;
+                const uint32_t h = T::hash(cur_word);
+                const int step = attempts++ >> 6;
+                ip = probe;
+                probe = ip + step;
+                if (probe > mflimit) { out_of_input = true; break; }
+                fwd_word = input_word(in, probe);
+                ref = (int)wv::uniform((uint32_t)table[h]);
+                if (lane == 0) table[h] = (entry)ip;
+                if (GENERIC && ref < ip - kMaxDistance) continue;     // lz4.c:427
+                if (input_word(in, ref) == cur_word) break;
+            }
+            if (out_of_input) break;
+
+            // ---- catch up: lz4.c:657 ----
+            {
+                const int room = ip - anchor, bound = room < ref ? room : ref;
+                const int back = bound > 0 ? wave_catch_up(in, ip, ref, bound) : 0;
+                ip -= back; ref -= back;
+            }
+
+            // ---- literals: lz4.c:660-691 ----
+            int ll = ip - anchor;
+            int token_at = op++;
+            if (op + ll + (ll >> 8) > cap - 8) return 0;             // lz4.c:663
+            uint32_t token = ll >= 15 ? 0xF0u : (uint32_t)(ll << 4);
+            // (the reference's limit tests under-estimate the length bytes by up to length/65280; it
+            //  can only then run past `cap` and return 0 from a later test -- same 0, no stray write)
+            if (ll >= 15 && op + (ll - 15) / 255 + 1 + ll > cap) return 0;
+            if (ll >= 15) op += put_length_bytes(out + op, ll - 15);
+            wave_copy(out + op, in + anchor, ll);
+            op += ll;
+
+            for (;;) {
+                // ---- offset, match length: lz4.c:693-733 ----
+                const uint32_t off = (uint32_t)(ip - ref) & 0xFFFFu;
+                if (op + 2 > cap) return 0;                           // (see note above)
+                if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
+                op += 2;
+                ip += kMinMatch; ref += kMinMatch; anchor = ip;
+                ip += wave_common_length(in, ip, ref, matchlimit);
+                const int extra = ip - anchor;
+                if (op + (extra >> 8) > cap - 6) return 0;           // lz4.c:728
+                if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return 0;   // (see note above)
+                token |= extra >= 15 ? 15u : (uint32_t)extra;
+                if (lane == 0) out[token_at] = (uint8_t)token;
+                if (extra >= 15) op += put_length_bytes(out + op, extra - 15);
+
+                if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
+                // ---- re-seed the table and test the next position: lz4.c:739-751 ----
+                {
+                    const uint32_t h2 = T::hash(input_word(in, ip - 2));
+                    if (lane == 0) table[h2] = (entry)(ip - 2);
+                    wv::mem_sync();
+                    cur_word = input_word(in, ip);
+                    const uint32_t h = T::hash(cur_word);
+                    ref = (int)wv::uniform((uint32_t)table[h]);
+                    if (lane == 0) table[h] = (entry)ip;
+                }
+                const bool in_range = !GENERIC || ref > ip - (kMaxDistance + 1);   // lz4.c:538
+                if (!(in_range && input_word(in, ref) == cur_word)) break;
+                token_at = op++;                                      // zero-literal sequence (lz4.c:751)
+                token = 0;
+            }
+            anchor = ip++;                                            // lz4.c:754-755
+            fwd_word = input_word(in, ip);
+        }
+    }
+tail:
+    {   // ---- last literals: lz4.c:758-767 ----
+        const int run = n - anchor;
+        if (op + run + 1 + (run - 15 + 255) / 255 > cap) return 0;   // lz4.c:762
+        if (lane == 0) out[op] = (uint8_t)(run >= 15 ? 0xF0 : (run << 4));
+        op++;
+        if (run >= 15) op += put_length_bytes(out + op, run - 15);
+        wave_copy(out + op, in + anchor, run);
+        op += run;
+    }
+    return op;
+}
+
+// One wavefront (= one workgroup of 64 threads) per block; 16 KiB of dynamic LDS per workgroup,
+// so up to 10 blocks are resident per CU.
+__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b)
+{
+    LZ4HIP_DYN_LDS(lds);
+    const int64_t blk = (int64_t)blockIdx.x;
+    if (blk >= b.n_blocks) return;
+    const int n = wv::uniform(batch_src_len(b, blk));
+    const int cap = wv::uniform(batch_dst_cap(b, blk));
+    const uint8_t* src = batch_src(b, blk);
+    uint8_t* dst = batch_dst(b, blk);
+    int r;
+    if (n < k64kLimit) r = encode_fast_block<false>(src, n, dst, cap, lds);      // lz4.c:783-785
+    else               r = encode_fast_block<true>(src, n, dst, cap, lds);
+    if (wv::lane() == 0) b.result[blk] = r;
+}
+
+}  // namespace lz4hip

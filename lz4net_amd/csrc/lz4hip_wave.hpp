@@ -1,0 +1,62 @@
+// lz4hip_wave.hpp -- gfx950 wavefront primitives used by every lz4hip kernel.
+//
+// A 64-lane wavefront is the unit that owns one LZ4 block.  Control state of the (inherently
+// sequential) LZ4 parse is kept wave-uniform in SGPRs; the 64 lanes are used for data movement,
+// match counting (ballot + ctz) and candidate evaluation.  This header is the ONLY place that names
+// AMDGCN builtins; kernels are written against the `wv::` API below.  (tests/simt/ provides a
+// CPU emulation of the same API so the kernel sources can be exercised without a GPU; that is
+// test infrastructure and is never linked into liblz4hip.so.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LZ4HIP_WAVE_API 1
+#define LZ4HIP_DEVICE __device__ __forceinline__
+// Dynamic LDS of the current workgroup, 16-byte aligned (cdna guide, Guideline 17).
+#define LZ4HIP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+namespace wv {
+
+constexpr int kWave = 64;
+
+LZ4HIP_DEVICE int lane() { return (int)(threadIdx.x & 63u); }
+LZ4HIP_DEVICE int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Promote a value the programmer knows to be wave-uniform into an SGPR.
+LZ4HIP_DEVICE uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+LZ4HIP_DEVICE int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+LZ4HIP_DEVICE uint64_t uniform(uint64_t v)
+{
+    uint32_t lo = uniform((uint32_t)v), hi = uniform((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+LZ4HIP_DEVICE int64_t uniform(int64_t v) { return (int64_t)uniform((uint64_t)v); }
+
+// Broadcast of the first active lane's value (v_readfirstlane); unlike uniform() the lanes may disagree.
+LZ4HIP_DEVICE uint64_t first_lane(uint64_t v) { return uniform(v); }
+
+// v_readlane_b32 with a wave-uniform lane index: result lands in an SGPR.
+LZ4HIP_DEVICE uint32_t readlane(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane); }
+
+// Arbitrary cross-lane gather (ds_bpermute_b32): lane i receives v from lane idx_i.
+LZ4HIP_DEVICE uint32_t shuffle(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+
+LZ4HIP_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
+LZ4HIP_DEVICE bool any(bool p) { return __ballot(p) != 0ull; }
+
+// Orders this wave's earlier memory operations before its later ones as seen by the OTHER lanes of
+// the same wave.  The hardware already executes a wave's vector-memory instructions in order; this
+// only stops the compiler from moving a load above a store it cannot see a same-thread dependence on.
+LZ4HIP_DEVICE void mem_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+LZ4HIP_DEVICE void block_sync() { __syncthreads(); }
+
+LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+LZ4HIP_DEVICE int popc64(uint64_t m) { return __builtin_popcountll(m); }
+
+}  // namespace wv

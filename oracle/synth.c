@@ -86,7 +86,11 @@ void lz4s_fill_batch(int dist, uint64_t seed, uint64_t first_block, int64_t n, u
 
 uint64_t lz4s_checksum(const uint8_t* p, int64_t n)
 {
-    uint64_t h = 0xCBF29CE484222325ull;
-    for (int64_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
-    return h;
+    uint64_t h = 0;
+    for (int64_t w = 0; w * 8 < n; w++) {
+        uint64_t v = 0;
+        for (int k = 0; k < 8 && w * 8 + k < n; k++) v |= (uint64_t)p[w * 8 + k] << (8 * k);
+        h += mix64(v + (uint64_t)w * 0xD1342543DE82EF95ull);
+    }
+    return h + mix64((uint64_t)(uint32_t)n);
 }

@@ -1,6 +1,6 @@
 /*
  * synth.h -- TEST INFRASTRUCTURE ONLY: CPU twins of the device-side synthetic block generators
- * (lz4net_amd/csrc/lz4hip_synth.hip).  Both sides must produce bit-identical bytes for the same
+ * (lz4net_amd/csrc/lz4hip_synth.hpp).  Both sides must produce bit-identical bytes for the same
  * (distribution, seed, block index, length) so that full-size GPU batches can be spot-checked
  * against the oracle without ever holding the batch in host memory.
  *
@@ -22,7 +22,7 @@ void lz4s_fill_block(int dist, uint64_t seed, uint64_t block_index, uint8_t* out
 /* n blocks, block i written at out + i*stride */
 void lz4s_fill_batch(int dist, uint64_t seed, uint64_t first_block, int64_t n, uint8_t* out,
                      int64_t stride, int len);
-/* FNV-style 64-bit checksum of a byte range; device twin in lz4hip_synth.hip */
+/* position-salted 64-bit word-sum checksum of a byte range; device twin: csrc/lz4hip_synth.hpp */
 uint64_t lz4s_checksum(const uint8_t* p, int64_t n);
 #ifdef __cplusplus
 }

@@ -1,0 +1,82 @@
+"""ctypes front-end for tests/simt/libsimt_kernels.so (TEST INFRASTRUCTURE): runs the real kernel
+sources under the CPU SIMT emulator.  Same call shapes as the GPU batch API so tests can share code."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt"))
+from build_emu import build  # noqa: E402
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.emu_compare.restype = C.c_ulonglong
+        _lib.emu_steps.restype = C.c_ulonglong
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def pack(rows, pad=16):
+    n = len(rows)
+    stride = max([len(r) for r in rows] + [1]) + pad
+    buf = np.zeros((n, stride), np.uint8)
+    for i, r in enumerate(rows):
+        buf[i, :len(r)] = r
+    return buf, np.array([len(r) for r in rows], np.int32)
+
+
+def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1):
+    src, sl = pack(comps)
+    if src_lens is not None:
+        sl = np.array(src_lens, np.int32)
+    caps = np.array(out_sizes, np.int32)
+    ds = max(int(caps.max()), 1) + 64
+    dst = np.full((len(comps), ds), 0xA5, np.uint8)
+    res = np.zeros(len(comps), np.int32)
+    lib().emu_decode(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
+                     _p(res), C.c_int64(len(comps)), waves_per_group)
+    return res, dst
+
+
+def encode(blocks, caps=None, hc=False, groups=2):
+    src, sl = pack(blocks)
+    if caps is None:
+        caps = [len(b) + len(b) // 255 + 16 for b in blocks]
+    caps = np.array(caps, np.int32)
+    ds = max(int(caps.max()), 1) + 64
+    dst = np.full((len(blocks), ds), 0xA5, np.uint8)
+    res = np.zeros(len(blocks), np.int32)
+    args = (_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
+    if hc:
+        lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
+    else:
+        lib().emu_encode_fast(*args)
+    return res, dst
+
+
+def synth(dist, seed, first_block, n, length, stride=None, block_step=1):
+    stride = length if stride is None else stride
+    out = np.zeros((n, max(stride, 1)), np.uint8)
+    lib().emu_synth(dist, C.c_uint64(seed), C.c_uint64(first_block), C.c_uint64(block_step), C.c_int64(n), _p(out), C.c_int64(out.shape[1]), length)
+    return out
+
+
+def checksum(rows):
+    buf, ln = pack(rows, pad=0)
+    sums = np.zeros(len(rows), np.uint64)
+    lib().emu_checksum(_p(buf), C.c_int64(buf.shape[1]), _p(ln), _p(sums), C.c_int64(len(rows)))
+    return sums
+
+
+def compare(a, b, lens):
+    lens = np.array(lens, np.int32)
+    return lib().emu_compare(_p(a), C.c_int64(a.shape[1]), _p(b), C.c_int64(b.shape[1]), _p(lens), C.c_int64(a.shape[0]))

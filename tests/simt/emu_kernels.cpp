@@ -1,0 +1,84 @@
+// emu_kernels.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the real kernel sources (lz4net_amd/csrc/*.hpp) against the SIMT emulator and exposes
+// them through a C ABI for tests/test_simt_emulation.py.  Built with g++, never shipped.
+#include "simt_wave.hpp"
+
+#include "lz4hip_common.hpp"
+#include "lz4hip_decode.hpp"
+#include "lz4hip_encode.hpp"
+#include "lz4hip_synth.hpp"
+#ifdef LZ4HIP_HAVE_HC
+#include "lz4hip_hc.hpp"
+#endif
+
+using namespace lz4hip;
+
+static Batch make_batch(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+{
+    Batch b;
+    memset(&b, 0, sizeof b);
+    b.src = src; b.src_stride = src_stride; b.src_len = src_len;
+    b.dst = dst; b.dst_stride = dst_stride; b.dst_cap = dst_cap;
+    b.result = result; b.n_blocks = n;
+    return b;
+}
+
+extern "C" {
+
+void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int waves_per_group)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    const unsigned wpg = (unsigned)waves_per_group;
+    dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
+    if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b); });
+    else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b); });
+}
+
+void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b); });
+}
+
+#ifdef LZ4HIP_HAVE_HC
+void emu_encode_hc(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                   int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups, int heads32)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    // chain slabs poisoned with a pattern that would derail any walk reading an unwritten slot
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)groups * kHcGlobalBytesPerGroup, 0x5A);
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* chains = ws.data() + 256;
+    const int lds = heads32 ? kHcLdsHeads32 : kHcLdsHeads16;
+    simt::launch(dim3((unsigned)groups), dim3(64), (size_t)lds, [=] { encode_hc_kernel(b, counter, chains, lds); });
+}
+#endif
+
+void emu_synth(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n, uint8_t* out, int64_t stride, int len)
+{
+    SynthArgs a = { out, stride, n, seed, first_block, block_step, len, dist };
+    unsigned grid = (dist <= 1) ? 3u : (unsigned)((n + 63) / 64);
+    simt::launch(dim3(grid), dim3(64), 0, [=] { synth_kernel(a); });
+}
+
+void emu_checksum(const uint8_t* data, int64_t stride, const int32_t* len, uint64_t* sums, int64_t n)
+{
+    ChecksumArgs a = { data, nullptr, stride, len, 0, sums, n };
+    simt::launch(dim3((unsigned)((n + 3) / 4)), dim3(256), 0, [=] { checksum_kernel(a); });
+}
+
+unsigned long long emu_compare(const uint8_t* x, int64_t xs, const uint8_t* y, int64_t ys, const int32_t* len, int64_t n)
+{
+    unsigned long long bad = 0;
+    CompareArgs c = { x, xs, y, ys, len, 0, n, &bad };
+    simt::launch(dim3((unsigned)((n + 3) / 4)), dim3(256), 0, [=] { compare_kernel(c); });
+    return bad;
+}
+
+unsigned long long emu_steps() { return simt::rt().steps; }
+}

@@ -1,0 +1,83 @@
+// simt_wave.hpp -- TEST INFRASTRUCTURE ONLY: CPU emulation of lz4net_amd/csrc/lz4hip_wave.hpp
+// (same `wv::` API, implemented on the fiber scheduler of simt.hpp).  Besides emulating the
+// semantics it CHECKS the uniformity claims the kernels make (wv::uniform / readlane index).
+#pragma once
+#include "simt.hpp"
+
+#define LZ4HIP_WAVE_API 1
+#define LZ4HIP_DEVICE inline
+#define LZ4HIP_DYN_LDS(name) unsigned char* name = simt::rt().lds.data()
+
+namespace wv {
+
+constexpr int kWave = 64;
+
+inline int lane() { return simt::rt().cur->tid & 63; }
+inline int wave_in_block() { return simt::rt().cur->tid >> 6; }
+
+inline uint64_t uniform64(uint64_t v, int site)
+{
+    unsigned p, tag;
+    const simt::Lane* w = simt::exchange(v, site, &p, &tag);
+    const int n = simt::wave_width(simt::rt().cur);
+    for (int i = 0; i < n; i++)
+        if (simt::took_part(w[i], p, tag)) {
+            if (w[i].slot[p] != v) simt::die("wv::uniform() on a value that is not wave-uniform", site, i);
+            return w[i].slot[p];
+        }
+    return v;
+}
+inline uint32_t uniform(uint32_t v) { return (uint32_t)uniform64(v, 101); }
+inline int32_t uniform(int32_t v) { return (int32_t)uniform64((uint32_t)v, 102); }
+inline uint64_t uniform(uint64_t v) { return uniform64(v, 103); }
+inline int64_t uniform(int64_t v) { return (int64_t)uniform64((uint64_t)v, 104); }
+
+inline uint64_t first_lane(uint64_t v)
+{
+    unsigned p, tag;
+    const simt::Lane* w = simt::exchange(v, 105, &p, &tag);
+    const int n = simt::wave_width(simt::rt().cur);
+    for (int i = 0; i < n; i++)
+        if (simt::took_part(w[i], p, tag)) return w[i].slot[p];
+    return v;
+}
+
+inline uint32_t readlane(uint32_t v, int src_lane)
+{
+    unsigned p, tag;
+    // the index must be wave-uniform on hardware (it is an SGPR operand): check it
+    const simt::Lane* w = simt::exchange(((uint64_t)(uint32_t)src_lane << 32) | v, 110, &p, &tag);
+    const int n = simt::wave_width(simt::rt().cur);
+    for (int i = 0; i < n; i++)
+        if (simt::took_part(w[i], p, tag) && (int)(w[i].slot[p] >> 32) != src_lane)
+            simt::die("wv::readlane() with a non-uniform lane index", src_lane, (int)(w[i].slot[p] >> 32));
+    if (src_lane < 0 || src_lane >= 64) simt::die("wv::readlane() lane out of range", src_lane);
+    return (uint32_t)w[src_lane].slot[p];
+}
+
+inline uint32_t shuffle(uint32_t v, int src_lane)
+{
+    unsigned p, tag;
+    const simt::Lane* w = simt::exchange(v, 120, &p, &tag);
+    return (uint32_t)w[src_lane & 63].slot[p];
+}
+
+inline uint64_t ballot(bool pred)
+{
+    unsigned p, tag;
+    const simt::Lane* w = simt::exchange(pred ? 1 : 0, 130, &p, &tag);
+    const int n = simt::wave_width(simt::rt().cur);
+    uint64_t m = 0;
+    for (int i = 0; i < n; i++)
+        if (simt::took_part(w[i], p, tag) && w[i].slot[p]) m |= 1ull << i;
+    return m;
+}
+inline bool any(bool pred) { return ballot(pred) != 0; }
+
+inline void mem_sync() { simt::yield(simt::WAIT_WAVE, 140); }
+inline void block_sync() { simt::yield(simt::WAIT_BLOCK, 150); }
+
+inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+
+}  // namespace wv

@@ -1,0 +1,92 @@
+"""-m gpu: device-resident batches (torch tensors -> lz4hip_*_batch_device), device-side synthetic
+generators, and the size-independent properties used at BASELINE.json's full batch sizes:
+encode -> decode round trip is the identity, results == lengths, checksum of checksums."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "no GPU visible to torch"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def test_device_generators_match_cpu_twins(torch_cuda, oracle):
+    from lz4net_amd import batch
+    for dist in range(4):
+        for length in (1, 100, 4096, 65536):
+            got = batch.synth(dist, 77, 1000, 5, length).cpu().numpy()
+            want = oracle.gen(dist, 77, 1000, 5, length)
+            assert np.array_equal(got, want), (dist, length)
+    t = batch.synth(2, 3, 10, 7, 65536)
+    sums = batch.checksum(t, 65536).cpu().numpy().view(np.uint64)
+    host = t.cpu().numpy()
+    assert [int(s) for s in sums] == [oracle.checksum(host[i]) for i in range(7)]
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("hc", [False, True])
+def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc):
+    torch = torch_cuda
+    from lz4net_amd import batch
+    n = 4096 if not hc else 512
+    raw = batch.synth(dist, 2024, 0, n)
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=hc)
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, batch.BLOCK, known_output_size=True)
+    assert bool((clen > 0).all()) and bool((used == clen).all())
+    assert batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    produced = batch.decode(comp, clen, back.zero_(), batch.BLOCK, known_output_size=False)
+    assert bool((produced == batch.BLOCK).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    # spot-check compressed bytes against the oracle on a deterministic sample
+    lens = clen.cpu().numpy()
+    for i in list(range(0, n, max(n // 16, 1))) + [n - 1]:
+        want = oracle.compress(oracle.gen(dist, 2024, i, 1)[0], hc=hc)
+        got = comp[i, :int(lens[i])].cpu().numpy()
+        assert lens[i] == len(want) and np.array_equal(got, want), (dist, hc, i)
+
+
+def test_full_size_decode_properties(torch_cuda, oracle):
+    """BASELINE config 2 shape (2^20 x 64 KiB, reduced only if the box has less memory): round trip is the
+    identity, every result equals the compressed length, checksum of checksums matches the input's."""
+    torch = torch_cuda
+    from lz4net_amd import batch
+    free, _ = torch.cuda.mem_get_info()
+    n = 1 << 20
+    while n * (2 * batch.BLOCK + batch.BOUND_STRIDE) * 1.05 > free and n > 1024:
+        n //= 2
+    raw = batch.synth(2, 7, 0, n)
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, batch.BLOCK)
+    assert bool((used == clen).all())
+    assert batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    a = batch.checksum(raw, batch.BLOCK)
+    b = batch.checksum(back, batch.BLOCK)
+    assert int(a.sum().item()) == int(b.sum().item()) and bool((a == b).all())
+    ratio = float(clen.double().mean().item()) / batch.BLOCK
+    assert 0.45 < ratio < 0.53, ratio            # fuzzer-style data compresses to ~0.487
+    lens = clen.cpu().numpy()
+    for i in (0, 1, n // 2, n - 1):
+        want = oracle.compress(oracle.gen(2, 7, i, 1)[0])
+        assert lens[i] == len(want) and np.array_equal(comp[i, :len(want)].cpu().numpy(), want), i
+
+
+def test_round_robin_sharding_single_process(torch_cuda, oracle):
+    # world_size-1 view of the N>1 path: the shard helper must reproduce global order
+    torch = torch_cuda
+    from lz4net_amd import batch
+    n, world = 37, 4
+    parts = []
+    for r in range(world):
+        cnt = batch.local_block_count(n, r, world)
+        idx = [batch.local_to_global(j, r, world) for j in range(cnt)]
+        assert all(i % world == r and i < n for i in idx)
+        parts.append(idx)
+    assert sorted(sum(parts, [])) == list(range(n))

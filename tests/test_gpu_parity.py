@@ -1,0 +1,229 @@
+"""-m gpu parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors (generated from the reference's own C).  Bit-exact for every byte and every
+return code.  Mirrors the reference's test strategy: cross-implementation identity
+(ConformanceTests.cs:59-68,121-148), round trips, and upstream's fuzzer matrix (original/fuzzer.c:176-227)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
+
+
+def sha(a):
+    return hashlib.sha256(bytes(a)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import gpu_helpers
+    from lz4net_amd import _lib
+    assert _lib.lib().lz4hip_device_count() >= 1, "no HIP device visible"
+    name = _lib.lib().lz4hip_codec_name().decode()
+    assert "gfx950" in name, name
+    return gpu_helpers
+
+
+def _blocks(oracle, sizes=SIZES, seeds=(5,)):
+    out = []
+    for dist in range(4):
+        for seed in seeds:
+            for n in sizes:
+                out.append(oracle.gen(dist, seed, n, 1, max(n, 1))[0][:n])
+    rng = np.random.default_rng(7)
+    for n in (50, 700, 9000, 65536):
+        for k in (2, 3, 16):
+            out.append(rng.integers(0, k, n, dtype=np.uint8))
+    out.append(np.frombuffer(b"abcabcabcabcabcabcabcabcabcabc" * 40, dtype=np.uint8))
+    return out
+
+
+def test_golden_synth_vectors(gpu, oracle):
+    # known answers from the reference's own C (tests/golden/make_golden.py); no oracle in the loop
+    es = GOLD["synth"]
+    blocks = [oracle.gen(e["dist"], e["seed"], e["block"], 1, max(e["n"], 1))[0][:e["n"]] for e in es]
+    for hc, klen, ksha in ((False, "fast_len", "fast_sha256"), (True, "hc_len", "hc_sha256")):
+        res, dst = gpu.encode(blocks, hc=hc)
+        for i, e in enumerate(es):
+            assert res[i] == e[klen], (i, hc, e["dist"], e["n"], res[i], e[klen])
+            assert sha(dst[i, :res[i]]) == e[ksha], (i, hc, e["dist"], e["n"])
+
+
+def test_fast_encode_bit_exact(gpu, oracle):
+    blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000, 200000), seeds=(5, 6))
+    res, dst = gpu.encode(blocks)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+        assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
+
+
+def test_hc_encode_bit_exact(gpu, oracle):
+    blocks = _blocks(oracle, sizes=SIZES + (65537, 70000, 150000), seeds=(5,))
+    res, dst = gpu.encode(blocks, hc=True)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+
+
+def test_limited_output(gpu, oracle):
+    # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
+    blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
+    for hc in (False, True):
+        lens = [len(oracle.compress(a, hc=hc)) for a in blocks]
+        for delta in (0, -1, -7):
+            caps = [max(l + delta, 0) for l in lens]
+            res, dst = gpu.encode(blocks, caps=caps, hc=hc)
+            for i, a in enumerate(blocks):
+                want = oracle.compress_raw(a, caps[i], hc=hc)[0]
+                assert res[i] == want, (i, hc, delta, res[i], want)
+                assert (dst[i, caps[i]:] == 0xA5).all(), (i, hc, delta, "wrote past the capacity")
+
+
+def test_decode_known_and_unknown(gpu, oracle):
+    blocks = _blocks(oracle)
+    for hc in (False, True):
+        comps = [oracle.compress(a, hc=hc) for a in blocks]
+        res, dst = gpu.decode(comps, [a.size for a in blocks], known=True)
+        for i, (a, c) in enumerate(zip(blocks, comps)):
+            assert res[i] == len(c), (i, hc, res[i], len(c))
+            assert np.array_equal(dst[i, :a.size], a), (i, hc)
+            assert (dst[i, a.size:] == 0xA5).all()
+        for extra in (0, 1, 100):
+            res, dst = gpu.decode(comps, [a.size + extra for a in blocks], known=False)
+            for i, a in enumerate(blocks):
+                assert res[i] == a.size, (i, hc, extra, res[i])
+                assert np.array_equal(dst[i, :a.size], a)
+                assert (dst[i, a.size + extra:] == 0xA5).all()
+
+
+def test_decode_error_codes(gpu, oracle):
+    rng = np.random.default_rng(11)
+    blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
+    comps = [oracle.compress(a) for a in blocks]
+    cases_k, want_k, cases_u, want_u = [], [], [], []
+    for a, c in zip(blocks, comps):
+        for osize in (a.size - 1, a.size + 1, a.size // 2):
+            cases_k.append((c, osize)); want_k.append(oracle.uncompress_raw(c, osize)[0])
+        for isz, mo in ((len(c), a.size - 1), (len(c) - 1, a.size), (len(c) + 1, a.size), (0, a.size)):
+            cases_u.append((c, isz, mo)); want_u.append(oracle.uncompress_unknown_raw(c, isz, mo)[0])
+        for _ in range(6):
+            cc = c.copy()
+            cc[rng.integers(0, len(c))] = rng.integers(0, 256)
+            cases_k.append((cc, a.size)); want_k.append(oracle.uncompress_raw(cc, a.size)[0])
+            cases_u.append((cc, len(cc), a.size)); want_u.append(oracle.uncompress_unknown_raw(cc, len(cc), a.size)[0])
+    pad = [np.concatenate([c, np.zeros(max(o, 0) + 1024, np.uint8)]) for c, o in cases_k]
+    res, dst = gpu.decode(pad, [o for _, o in cases_k], known=True)
+    for i, w in enumerate(want_k):
+        assert res[i] == w, ("known", i, res[i], w)
+        assert (dst[i, max(cases_k[i][1], 0):] == 0xA5).all()
+    padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c, _, _ in cases_u]
+    res, dst = gpu.decode(padu, [mo for _, _, mo in cases_u], known=False, src_lens=[i for _, i, _ in cases_u])
+    for i, w in enumerate(want_u):
+        assert res[i] == w, ("unknown", i, res[i], w)
+        assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
+
+
+def test_fuzzer_matrix(gpu, oracle):
+    # original/fuzzer.c:149-227 on 32 KiB fuzzer-generated buffers, batched
+    LEN, N = 1 << 15, 96
+    blocks = [oracle.gen(2, 99, i, 1, LEN)[0] for i in range(N)]
+    bound = LEN + LEN // 255 + 16
+    rh, dh = gpu.encode(blocks, hc=True)
+    rf, df = gpu.encode(blocks, hc=False)
+    assert (rh > 0).all() and (rf > 0).all()
+    comps = [df[i, :rf[i]].copy() for i in range(N)]
+    for i in range(N):
+        assert np.array_equal(comps[i], oracle.compress(blocks[i])), i
+        assert np.array_equal(dh[i, :rh[i]], oracle.compress(blocks[i], hc=True)), i
+    r, d = gpu.decode(comps, [LEN] * N, known=True)
+    assert (r == rf).all() and all(np.array_equal(d[i, :LEN], blocks[i]) for i in range(N))
+    pad = [np.concatenate([c, np.zeros(LEN + 1024, np.uint8)]) for c in comps]
+    assert (gpu.decode(pad, [LEN - 1] * N, known=True)[0] < 0).all()      # one byte missing => must fail
+    assert (gpu.decode(pad, [LEN + 1] * N, known=True)[0] < 0).all()      # one byte too much => must fail
+    assert (gpu.decode(comps, [LEN + 1] * N, known=False)[0] == LEN).all()
+    assert (gpu.decode(comps, [LEN] * N, known=False)[0] == LEN).all()
+    assert (gpu.decode(comps, [LEN - 1] * N, known=False)[0] < 0).all()
+    padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c in comps]
+    assert (gpu.decode(padu, [LEN] * N, known=False, src_lens=[len(c) - 1 for c in comps])[0] < 0).all()
+    assert (gpu.decode(padu, [LEN] * N, known=False, src_lens=[len(c) + 1 for c in comps])[0] < 0).all()
+    # compress into exactly the needed size works, one byte less returns 0 without touching the canary
+    r, d = gpu.encode(blocks, caps=list(rf))
+    assert (r == rf).all() and all((d[i, rf[i]:] == 0xA5).all() for i in range(N))
+    r, d = gpu.encode(blocks, caps=[x - 1 for x in rf])
+    assert (r == 0).all() and all((d[i, rf[i] - 1:] == 0xA5).all() for i in range(N))
+    r, d = gpu.encode(blocks, caps=list(rh), hc=True)
+    assert (r == rh).all()
+    r, d = gpu.encode(blocks, caps=[x - 1 for x in rh], hc=True)
+    assert (r == 0).all() and all((d[i, rh[i] - 1:] == 0xA5).all() for i in range(N))
+    # issue 52 overflow regression (original/fuzzer.c:96-117): a 16 MiB run of 0xFF length bytes
+    bad = np.full(16840000, 0xFF, np.uint8)
+    bad[:3] = (0x0F, 0, 0)
+    assert gpu.decode([bad], [20 << 20], known=True)[0][0] < 0
+
+
+def test_lz4codec_api(gpu, oracle):
+    # the reference's load-time self test (src/LZ4/LZ4Codec.cs:173-239): Lorem x5, fast + HC,
+    # known + unknown length; plus WrapTests (src/LZ4.Tests/WrapTests.cs:11-48)
+    from lz4net_amd import LZ4Codec
+    from lz4net_amd.codec import ArgumentException, ArgumentNullException
+    e = next(x for x in GOLD["inline"] if x["name"] == "lorem_x5")
+    original = bytes.fromhex(e["input_hex"])
+    for enc, key in ((LZ4Codec.Encode, "fast_hex"), (LZ4Codec.EncodeHC, "hc_hex")):
+        comp = enc(original, 0, len(original))
+        assert comp.hex() == e[key]
+        out = bytearray(len(original))
+        assert LZ4Codec.Decode(comp, 0, len(comp), out, 0, len(out), True) == len(original)
+        assert bytes(out) == original
+        out = bytearray(len(original) + 50)
+        assert LZ4Codec.Decode(comp, 0, len(comp), out, 0, len(out), False) == len(original)
+        assert bytes(out[:len(original)]) == original
+        assert LZ4Codec.Decode(comp, 0, len(comp), len(original)) == original
+        with pytest.raises(ArgumentException):
+            LZ4Codec.Decode(comp, 0, len(comp) - 1, bytearray(len(original)), 0, len(original), True)
+    assert LZ4Codec.MaximumOutputLength(65536) == 65809
+    assert "gfx950" in LZ4Codec.CodecName
+    assert LZ4Codec.Encode(b"", 0, 0, bytearray(10), 0, 10) == 0              # inputLength == 0 => 0
+    with pytest.raises(ArgumentNullException):
+        LZ4Codec.Encode(None, 0, 5, bytearray(10), 0, 10)
+    with pytest.raises(ArgumentException):
+        LZ4Codec.Encode(b"abc", 2, 5, bytearray(10), 0, 10)
+    assert LZ4Codec.Encode(original, 0, len(original), bytearray(10), 0, 10) == 0   # too small => 0
+    assert LZ4Codec.EncodeHC(original, 0, len(original), bytearray(10), 0, 10) == -1  # HC maps <=0 to -1
+    lorem4 = bytes.fromhex(next(x for x in GOLD["inline"] if x["name"] == "lorem_x1")["input_hex"]) * 4
+    rnd = bytes(np.random.default_rng(0).integers(0, 256, 2048, dtype=np.uint8))
+    for wrap in (LZ4Codec.Wrap, LZ4Codec.WrapHC):
+        w = wrap(lorem4)
+        assert len(w) < len(lorem4) and LZ4Codec.Unwrap(w) == lorem4
+        w = wrap(rnd)
+        assert len(w) == len(rnd) + 8 and LZ4Codec.Unwrap(w) == rnd       # incompressible: stored raw
+        assert LZ4Codec.Unwrap(wrap(b"x")) == b"x"
+        assert wrap(b"") == bytes(8)
+
+
+def test_lz4h_shaped_single_block_calls(gpu, oracle):
+    import ctypes as C
+    from lz4net_amd import _lib
+    L = _lib.lib()
+    a = oracle.gen(3, 4, 0, 1, 65536)[0]
+    out = np.zeros(65809 + 1, np.uint8)
+    n = L.lz4hip_compress(a.ctypes.data, out.ctypes.data, a.size)
+    want = oracle.compress(a)
+    assert n == len(want) and np.array_equal(out[:n], want)
+    nh = L.lz4hip_compressHC(a.ctypes.data, out.ctypes.data, a.size)
+    wanth = oracle.compress(a, hc=True)
+    assert nh == len(wanth) and np.array_equal(out[:nh], wanth)
+    back = np.zeros(a.size, np.uint8)
+    comp = np.ascontiguousarray(want)
+    assert L.lz4hip_uncompress(comp.ctypes.data, back.ctypes.data, a.size) == len(want)   # no source length given
+    assert np.array_equal(back, a)
+    back[:] = 0
+    assert L.lz4hip_uncompress_unknownOutputSize(comp.ctypes.data, back.ctypes.data, len(want), a.size) == a.size
+    assert np.array_equal(back, a)
