@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--hc-blocks", type=int, default=1 << 14, help="blocks for the LZ4HC extra (0 = skip)")
+    ap.add_argument("--decoder", choices=["auto", "lane", "wave"], default="auto",
+                    help="block->hardware mapping of the decoder (auto = library default)")
+    ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
 
 
@@ -56,12 +59,12 @@ def event_ms(fn, torch):
 class Workload:
     """One distribution's device-resident batch: raw blocks, compressed blocks, lengths, decode target."""
 
-    def __init__(self, torch, batch, dist, seed, first_block, n, block_step=1):
+    def __init__(self, torch, batch, dist, seed, first_block, n, block_step=1, dst_pad=0):
         self.torch, self.batch, self.dist, self.n = torch, batch, dist, n
         self.raw = batch.synth(dist, seed, first_block, n, block_step=block_step)
         self.comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
         self.clen = torch.empty(n, dtype=torch.int32, device="cuda")
-        self.back = torch.empty_like(self.raw)
+        self.back = torch.empty((n, batch.BLOCK + dst_pad), dtype=torch.uint8, device="cuda")
         self.used = torch.empty(n, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         # warm-up launch on a sliver (module load, LDS config), then the timed single-pass encode
@@ -161,11 +164,14 @@ def main():
     n = args.blocks
     free, total = torch.cuda.mem_get_info()
     per_block = 2 * batch.BLOCK + batch.BOUND_STRIDE + 16
+    per_block += args.dst_pad
     while n * per_block * 1.03 > free and n > 1024:
         n //= 2
     # round-robin shard of a global batch of n*world blocks: local block j is global block j*world + rank
     seed = args.seed
-    wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world)
+    if args.decoder != "auto":
+        os.environ["LZ4HIP_DECODER"] = args.decoder
+    wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world, dst_pad=args.dst_pad)
     for _ in range(max(args.warmup, 0)):
         wl.decode_step()
     barrier()
@@ -199,21 +205,44 @@ def main():
     }
     extras[DIST_NAMES[args.dist]] = head
     alg_bytes_local, mean_kernel_ms = wl.algorithmic_bytes, sum(kernel_ms) / len(kernel_ms)
+    if world == 1 and not args.no_extras and args.decoder == "auto":
+        for name in ("lane", "wave"):
+            os.environ["LZ4HIP_DECODER"] = name
+            wl.back.zero_()
+            wl.decode_step()
+            torch.cuda.synchronize()
+            t = min(event_ms(wl.decode_step, torch) for _ in range(2))
+            head[f"decode_{name}_GBps"] = round(wl.raw_bytes / (t / 1e3) / 1e9, 2)
+            head[f"decode_{name}_ok"] = wl.verify()
+        del os.environ["LZ4HIP_DECODER"]
     if world == 1 and not args.no_extras:
         del wl
         torch.cuda.empty_cache()
         for d in range(4):
             if d == args.dist:
                 continue
-            w = Workload(torch, batch, d, seed, 0, n)
+            w = Workload(torch, batch, d, seed, 0, n, dst_pad=args.dst_pad)
             w.decode_step()
             torch.cuda.synchronize()
             ms = [event_ms(w.decode_step, torch) for _ in range(3)]
+            ok_default = w.verify()
+            alt = {}
+            if args.decoder == "auto":          # A/B: the other mapping on the same batch
+                for name in ("lane", "wave"):
+                    os.environ["LZ4HIP_DECODER"] = name
+                    w.back.zero_()
+                    w.decode_step()
+                    torch.cuda.synchronize()
+                    t = min(event_ms(w.decode_step, torch) for _ in range(2))
+                    alt[f"decode_{name}_GBps"] = round(w.raw_bytes / (t / 1e3) / 1e9, 2)
+                    alt[f"decode_{name}_ok"] = w.verify()
+                del os.environ["LZ4HIP_DECODER"]
             extras[DIST_NAMES[d]] = {
+                **alt,
                 "decode_GBps": round(w.raw_bytes / (min(ms) / 1e3) / 1e9, 2),
                 "decode_frac_of_hbm_peak": round(w.algorithmic_bytes / (min(ms) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                 "encode_fast_GBps": round(w.raw_bytes / (w.encode_ms / 1e3) / 1e9, 2),
-                "ratio": round(w.comp_bytes / w.raw_bytes, 4), "blocks": n, "roundtrip_ok": w.verify(),
+                "ratio": round(w.comp_bytes / w.raw_bytes, 4), "blocks": n, "roundtrip_ok": ok_default,
             }
             del w
             torch.cuda.empty_cache()

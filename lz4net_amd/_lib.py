@@ -54,6 +54,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        try:
+            # torch wheels bundle their own libamdhip64 / libhsa-runtime64.  Loading torch FIRST makes the
+            # dynamic linker resolve our DT_NEEDED entries to those same copies, so the process has ONE
+            # HIP/HSA runtime (two HSA runtimes in one process do not both see the GPU).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         so = _build.build()                     # raises if the library cannot be produced
         handle = C.CDLL(so)
         for name, restype, argtypes in SYMBOLS:

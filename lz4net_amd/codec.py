@@ -169,7 +169,10 @@ class LZ4Codec(metaclass=_LZ4CodecMeta):
     def Decode(cls, input, inputOffset=0, inputLength=-1, output=None, outputOffset=0, outputLength=0,
                knownOutputLength=False):
         """Decode(input, inputOffset, inputLength, output, outputOffset, outputLength=0, knownOutputLength=false)
-        -> bytes written, or (output=None) Decode(input, inputOffset, inputLength, outputLength) -> bytes."""
+        -> bytes written, or the allocating overload Decode(input, inputOffset, inputLength, outputLength) -> bytes
+        (4th positional argument an int, or output=None with outputLength given)."""
+        if isinstance(output, int):
+            output, outputLength = None, output
         if output is not None:
             inp_a = None if input is None else _as_bytes(input, "input")
             out_a = _as_bytes(output, "output")

@@ -6,12 +6,14 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
+#include "lz4hip_decode_lane.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -148,9 +150,23 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
 {
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
-    const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
-    if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d);
-    else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d);
+    // Two mappings of the same decoder (see lz4hip_decode_lane.hpp): one lane per block hides the
+    // per-sequence memory latency and is the default for batches; one wavefront per block streams
+    // long copies at full width and is used when there are too few blocks to fill the lanes.
+    // LZ4HIP_DECODER=wave|lane overrides (profiling / A-B runs).
+    const char* force = getenv("LZ4HIP_DECODER");
+    bool lane_per_block = d.n_blocks >= 4096;
+    if (force && force[0] == 'w') lane_per_block = false;
+    if (force && force[0] == 'l') lane_per_block = true;
+    if (lane_per_block) {
+        const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
+        if (known) hipLaunchKernelGGL(decode_lane_kernel<true>, dim3(grid), dim3(64), 0, stream, d);
+        else       hipLaunchKernelGGL(decode_lane_kernel<false>, dim3(grid), dim3(64), 0, stream, d);
+    } else {
+        const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
+        if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d);
+        else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -34,7 +34,7 @@ def pack(rows, pad=16):
     return buf, np.array([len(r) for r in rows], np.int32)
 
 
-def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1):
+def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=False):
     src, sl = pack(comps)
     if src_lens is not None:
         sl = np.array(src_lens, np.int32)
@@ -42,8 +42,12 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1):
     ds = max(int(caps.max()), 1) + 64
     dst = np.full((len(comps), ds), 0xA5, np.uint8)
     res = np.zeros(len(comps), np.int32)
-    lib().emu_decode(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
-                     _p(res), C.c_int64(len(comps)), waves_per_group)
+    if lane:
+        lib().emu_decode_lane(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
+                              _p(res), C.c_int64(len(comps)))
+    else:
+        lib().emu_decode(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
+                         _p(res), C.c_int64(len(comps)), waves_per_group)
     return res, dst
 
 

@@ -5,6 +5,7 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
+#include "lz4hip_decode_lane.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
@@ -34,6 +35,15 @@ void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t
     dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
     if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b); });
     else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b); });
+}
+
+void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (known) simt::launch(grid, block, 0, [=] { decode_lane_kernel<true>(b); });
+    else       simt::launch(grid, block, 0, [=] { decode_lane_kernel<false>(b); });
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

@@ -30,9 +30,11 @@ def test_device_generators_match_cpu_twins(torch_cuda, oracle):
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
 @pytest.mark.parametrize("hc", [False, True])
-def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc):
+@pytest.mark.parametrize("decoder", ["wave", "lane"])
+def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc, decoder, monkeypatch):
     torch = torch_cuda
     from lz4net_amd import batch
+    monkeypatch.setenv("LZ4HIP_DECODER", decoder)
     n = 4096 if not hc else 512
     raw = batch.synth(dist, 2024, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")

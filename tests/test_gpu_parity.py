@@ -87,7 +87,15 @@ def test_limited_output(gpu, oracle):
                 assert (dst[i, caps[i]:] == 0xA5).all(), (i, hc, delta, "wrote past the capacity")
 
 
-def test_decode_known_and_unknown(gpu, oracle):
+@pytest.fixture(params=["wave", "lane"])
+def decoder(request):
+    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane.hpp)."""
+    os.environ["LZ4HIP_DECODER"] = request.param
+    yield request.param
+    del os.environ["LZ4HIP_DECODER"]
+
+
+def test_decode_known_and_unknown(gpu, oracle, decoder):
     blocks = _blocks(oracle)
     for hc in (False, True):
         comps = [oracle.compress(a, hc=hc) for a in blocks]
@@ -104,7 +112,7 @@ def test_decode_known_and_unknown(gpu, oracle):
                 assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-def test_decode_error_codes(gpu, oracle):
+def test_decode_error_codes(gpu, oracle, decoder):
     rng = np.random.default_rng(11)
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -131,7 +139,7 @@ def test_decode_error_codes(gpu, oracle):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-def test_fuzzer_matrix(gpu, oracle):
+def test_fuzzer_matrix(gpu, oracle, decoder):
     # original/fuzzer.c:149-227 on 32 KiB fuzzer-generated buffers, batched
     LEN, N = 1 << 15, 96
     blocks = [oracle.gen(2, 99, i, 1, LEN)[0] for i in range(N)]

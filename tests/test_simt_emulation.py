@@ -25,29 +25,32 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-def test_decode_known_size(oracle):
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
         comps = [oracle.compress(a, hc=hc) for a in blocks]
-        res, dst = emu.decode(comps, [a.size for a in blocks], known=True, waves_per_group=2)
+        res, dst = emu.decode(comps, [a.size for a in blocks], known=True, waves_per_group=2, lane=lane)
         for i, (a, c) in enumerate(zip(blocks, comps)):
             assert res[i] == len(c), (i, hc, res[i], len(c))
             assert np.array_equal(dst[i, :a.size], a), (i, hc)
             assert (dst[i, a.size:] == 0xA5).all(), (i, hc, "wrote past the block")
 
 
-def test_decode_unknown_size(oracle):
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
     for extra in (0, 1, 100):
-        res, dst = emu.decode(comps, [a.size + extra for a in blocks], known=False)
+        res, dst = emu.decode(comps, [a.size + extra for a in blocks], known=False, lane=lane)
         for i, (a, c) in enumerate(zip(blocks, comps)):
             assert res[i] == a.size, (i, extra, res[i])
             assert np.array_equal(dst[i, :a.size], a)
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-def test_decode_error_codes_match_oracle(oracle):
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
@@ -65,12 +68,12 @@ def test_decode_error_codes_match_oracle(oracle):
             cases_u.append((cc, len(cc), a.size)); want_u.append(oracle.uncompress_unknown_raw(cc, len(cc), a.size)[0])
     # known-size: give the kernel a generous source length (zero padded) like the oracle wrapper does
     pad = [np.concatenate([c, np.zeros(max(o, 0) + 1024, np.uint8)]) for c, o in cases_k]
-    res, dst = emu.decode(pad, [o for _, o in cases_k], known=True)
+    res, dst = emu.decode(pad, [o for _, o in cases_k], known=True, lane=lane)
     for i, w in enumerate(want_k):
         assert res[i] == w, ("known", i, res[i], w)
         assert (dst[i, max(cases_k[i][1], 0):] == 0xA5).all()
     padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c, _, _ in cases_u]
-    res, dst = emu.decode(padu, [mo for _, _, mo in cases_u], known=False, src_lens=[i for _, i, _ in cases_u])
+    res, dst = emu.decode(padu, [mo for _, _, mo in cases_u], known=False, src_lens=[i for _, i, _ in cases_u], lane=lane)
     for i, w in enumerate(want_u):
         assert res[i] == w, ("unknown", i, res[i], w)
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
