@@ -294,7 +294,10 @@ def main():
             "frac_of_aggregate_hbm_peak": round(float(stats[0].item()) / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "lz4hip::decode_kernel<true>",
+            "bound": "hbm",
+            "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if args.decoder == "wave" or
+                       (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
+                       else "lz4hip::decode_lane_kernel<true> (one lane per block)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

@@ -150,22 +150,33 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
 {
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
-    // Two mappings of the same decoder (see lz4hip_decode_lane.hpp): one lane per block hides the
-    // per-sequence memory latency and is the default for batches; one wavefront per block streams
-    // long copies at full width and is used when there are too few blocks to fill the lanes.
-    // LZ4HIP_DECODER=wave|lane overrides (profiling / A-B runs).
+    // Two mappings of the same decoder (lz4hip_decode.hpp: one wavefront per block, coalesced wide copies;
+    // lz4hip_decode_lane.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
+    // partitioned per block by block_selected(): two launches, each skipping the other's blocks.
+    // Small batches cannot fill the lanes and use the wavefront mapping only.
+    // LZ4HIP_DECODER=wave|lane forces one mapping for every block (profiling / A-B runs).
     const char* force = getenv("LZ4HIP_DECODER");
-    bool lane_per_block = d.n_blocks >= 4096;
-    if (force && force[0] == 'w') lane_per_block = false;
-    if (force && force[0] == 'l') lane_per_block = true;
-    if (lane_per_block) {
+    int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
+    if (d.n_blocks < 4096 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
+    else if (force && force[0] == 'l') { lane_filter = kAllBlocks; wave_filter = -1; }
+    if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        if (known) hipLaunchKernelGGL(decode_lane_kernel<true>, dim3(grid), dim3(64), 0, stream, d);
-        else       hipLaunchKernelGGL(decode_lane_kernel<false>, dim3(grid), dim3(64), 0, stream, d);
-    } else {
+        // Residency throttle: the kernel uses no LDS; reserving some caps the wavefronts per CU so that the
+        // cache lines the resident lanes are streaming through (one input, one output, match sources per
+        // lane) stay in the XCD's L2.  LZ4HIP_LANE_LDS_KB overrides (tuning runs).
+        unsigned lds = kLaneDecodeLdsBytes;
+        if (const char* e = getenv("LZ4HIP_LANE_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
+        if (lds > 65536u) {
+            HIP_TRY(hipFuncSetAttribute((const void*)decode_lane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)decode_lane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (known) hipLaunchKernelGGL(decode_lane_kernel<true>, dim3(grid), dim3(64), lds, stream, d, lane_filter);
+        else       hipLaunchKernelGGL(decode_lane_kernel<false>, dim3(grid), dim3(64), lds, stream, d, lane_filter);
+    }
+    if (wave_filter >= 0) {
         const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
-        if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d);
-        else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d);
+        if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
+        else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
     }
     HIP_TRY(hipGetLastError());
     return 0;

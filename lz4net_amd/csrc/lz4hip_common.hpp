@@ -45,6 +45,17 @@ LZ4HIP_DEVICE uint8_t* batch_dst(const Batch& b, int64_t i) { return b.dst + (b.
 LZ4HIP_DEVICE int32_t batch_src_len(const Batch& b, int64_t i) { return b.src_len ? b.src_len[i] : b.src_len_all; }
 LZ4HIP_DEVICE int32_t batch_dst_cap(const Batch& b, int64_t i) { return b.dst_cap ? b.dst_cap[i] : b.dst_cap_all; }
 
+// Which blocks a decode launch handles.  A batch is decoded by two launches that partition it: blocks
+// that are essentially long copies (compressed to < 1/8, or > 90 % literals) stream best with one
+// wavefront per block, everything else (many short sequences) with one lane per block.
+enum BlockFilter { kAllBlocks = 0, kStreamingBlocks = 1, kFineGrainedBlocks = 2 };
+LZ4HIP_DEVICE bool block_selected(int filter, int src_len, int out_size)
+{
+    if (filter == kAllBlocks) return true;
+    const bool streaming = (int64_t)src_len * 8 < out_size || (int64_t)src_len * 10 > (int64_t)out_size * 9;
+    return streaming == (filter == kStreamingBlocks);
+}
+
 // Unaligned little-endian loads/stores (gfx950 runs with unaligned access enabled; hipcc lowers
 // these to single global_load/store_dword[xN] instructions).
 LZ4HIP_DEVICE uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }

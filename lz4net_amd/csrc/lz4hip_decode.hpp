@@ -191,12 +191,13 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
 
 // grid: ceil(n_blocks / waves_per_group) workgroups of 64 * waves_per_group threads.
 template <bool KNOWN>
-__global__ void __launch_bounds__(256) decode_kernel(Batch b)
+__global__ void __launch_bounds__(256) decode_kernel(Batch b, int filter)
 {
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv::wave_in_block();
     if (blk >= b.n_blocks) return;
     const int src_len = wv::uniform(batch_src_len(b, blk));
     const int out_size = wv::uniform(batch_dst_cap(b, blk));
+    if (!block_selected(filter, src_len, out_size)) return;
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);
     const int r = decode_block<KNOWN>(src, src_len, dst, out_size);

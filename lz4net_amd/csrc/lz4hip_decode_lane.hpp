@@ -24,6 +24,8 @@
 
 namespace lz4hip {
 
+constexpr unsigned kLaneDecodeLdsBytes = 0;   // dynamic LDS reserved per 64-lane workgroup purely to bound residency (tuned on hardware)
+
 LZ4HIP_DEVICE uint64_t load_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 LZ4HIP_DEVICE void store_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 
@@ -148,11 +150,13 @@ LZ4HIP_DEVICE int lane_decode_block(const uint8_t* __restrict__ src, int iend, u
 
 // grid: ceil(n_blocks / 64) workgroups of 64 threads; lane i of workgroup g decodes block g*64 + i.
 template <bool KNOWN>
-__global__ void __launch_bounds__(64) decode_lane_kernel(Batch b)
+__global__ void __launch_bounds__(64) decode_lane_kernel(Batch b, int filter)
 {
     const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk >= b.n_blocks) return;
-    b.result[blk] = lane_decode_block<KNOWN>(batch_src(b, blk), batch_src_len(b, blk), batch_dst(b, blk), batch_dst_cap(b, blk));
+    const int src_len = batch_src_len(b, blk), out_size = batch_dst_cap(b, blk);
+    if (!block_selected(filter, src_len, out_size)) return;
+    b.result[blk] = lane_decode_block<KNOWN>(batch_src(b, blk), src_len, batch_dst(b, blk), out_size);
 }
 
 }  // namespace lz4hip

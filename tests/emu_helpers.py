@@ -34,20 +34,22 @@ def pack(rows, pad=16):
     return buf, np.array([len(r) for r in rows], np.int32)
 
 
-def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=False):
+def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=False, auto=False):
     src, sl = pack(comps)
     if src_lens is not None:
         sl = np.array(src_lens, np.int32)
     caps = np.array(out_sizes, np.int32)
     ds = max(int(caps.max()), 1) + 64
     dst = np.full((len(comps), ds), 0xA5, np.uint8)
-    res = np.zeros(len(comps), np.int32)
-    if lane:
-        lib().emu_decode_lane(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
-                              _p(res), C.c_int64(len(comps)))
+    res = np.full(len(comps), -12345678, np.int32)
+    args = (int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(comps)))
+    if auto:        # the library's default: the batch is partitioned between the two mappings
+        lib().emu_decode_lane(*args, 2)
+        lib().emu_decode(*args, waves_per_group, 1)
+    elif lane:
+        lib().emu_decode_lane(*args, 0)
     else:
-        lib().emu_decode(int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps),
-                         _p(res), C.c_int64(len(comps)), waves_per_group)
+        lib().emu_decode(*args, waves_per_group, 0)
     return res, dst
 
 

@@ -28,22 +28,22 @@ static Batch make_batch(const uint8_t* src, int64_t src_stride, const int32_t* s
 extern "C" {
 
 void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int waves_per_group)
+                int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int waves_per_group, int filter)
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     const unsigned wpg = (unsigned)waves_per_group;
     dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
-    if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b); });
-    else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b); });
+    if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b, filter); });
+    else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b, filter); });
 }
 
 void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter)
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (known) simt::launch(grid, block, 0, [=] { decode_lane_kernel<true>(b); });
-    else       simt::launch(grid, block, 0, [=] { decode_lane_kernel<false>(b); });
+    if (known) simt::launch(grid, block, 0, [=] { decode_lane_kernel<true>(b, filter); });
+    else       simt::launch(grid, block, 0, [=] { decode_lane_kernel<false>(b, filter); });
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

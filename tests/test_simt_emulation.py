@@ -37,6 +37,15 @@ def test_decode_known_size(oracle, lane):
             assert (dst[i, a.size:] == 0xA5).all(), (i, hc, "wrote past the block")
 
 
+def test_decode_partitioned_between_mappings(oracle):
+    # default dispatch: every block is decoded by exactly one of the two mappings
+    blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
+    comps = [oracle.compress(a) for a in blocks]
+    res, dst = emu.decode(comps, [a.size for a in blocks], known=True, auto=True)
+    for i, (a, c) in enumerate(zip(blocks, comps)):
+        assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
+
+
 @pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
