@@ -7,6 +7,7 @@
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
+#include "lz4hip_decode_staged.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_synth.hpp"
@@ -158,8 +159,31 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     const char* force = getenv("LZ4HIP_DECODER");
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
     if (d.n_blocks < 4096 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
-    else if (force && force[0] == 'l') { lane_filter = kAllBlocks; wave_filter = -1; }
-    if (lane_filter >= 0) {
+    else if (force && (force[0] == 'l' || force[0] == 's')) { lane_filter = kAllBlocks; wave_filter = -1; }
+    bool staged = kStagedByDefault;
+    if (force && force[0] == 's') staged = true;
+    if (force && force[0] == 'l') staged = false;
+    if (lane_filter >= 0 && staged) {
+        // lane-per-block with a per-lane output ring in LDS (lz4hip_decode_staged.hpp)
+        const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
+        int ring = kStagedRingBytes;
+        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
+        const unsigned lds = 64u * (unsigned)ring;
+#define LZ4HIP_LAUNCH_STAGED(R)                                                                                      \
+        do {                                                                                                          \
+            if (lds > 65536u) {                                                                                       \
+                HIP_TRY(hipFuncSetAttribute((const void*)decode_staged_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+                HIP_TRY(hipFuncSetAttribute((const void*)decode_staged_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            }                                                                                                         \
+            if (known) hipLaunchKernelGGL((decode_staged_kernel<true, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);   \
+            else       hipLaunchKernelGGL((decode_staged_kernel<false, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);  \
+        } while (0)
+        if (ring == 256) LZ4HIP_LAUNCH_STAGED(256);
+        else if (ring == 1024) LZ4HIP_LAUNCH_STAGED(1024);
+        else if (ring == 2048) LZ4HIP_LAUNCH_STAGED(2048);
+        else LZ4HIP_LAUNCH_STAGED(512);
+#undef LZ4HIP_LAUNCH_STAGED
+    } else if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
         // Residency throttle: the kernel uses no LDS; reserving some caps the wavefronts per CU so that the
         // cache lines the resident lanes are streaming through (one input, one output, match sources per

@@ -6,6 +6,7 @@
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
+#include "lz4hip_decode_staged.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
@@ -44,6 +45,20 @@ void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const in
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
     if (known) simt::launch(grid, block, 0, [=] { decode_lane_kernel<true>(b, filter); });
     else       simt::launch(grid, block, 0, [=] { decode_lane_kernel<false>(b, filter); });
+}
+
+void emu_decode_staged(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                       int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (ring == 256) {
+        if (known) simt::launch(grid, block, 64 * 256, [=] { decode_staged_kernel<true, 256>(b, filter); });
+        else       simt::launch(grid, block, 64 * 256, [=] { decode_staged_kernel<false, 256>(b, filter); });
+    } else {
+        if (known) simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<true, 512>(b, filter); });
+        else       simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<false, 512>(b, filter); });
+    }
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

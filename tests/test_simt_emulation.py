@@ -11,6 +11,12 @@ from oracle.oracle import compress_bound
 SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
+def _mapping(m):
+    if isinstance(m, str):
+        return dict(staged=int(m[6:]))
+    return dict(lane=m)
+
+
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     out = []
     for dist in range(4):
@@ -25,12 +31,12 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
 def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
         comps = [oracle.compress(a, hc=hc) for a in blocks]
-        res, dst = emu.decode(comps, [a.size for a in blocks], known=True, waves_per_group=2, lane=lane)
+        res, dst = emu.decode(comps, [a.size for a in blocks], known=True, waves_per_group=2, **_mapping(lane))
         for i, (a, c) in enumerate(zip(blocks, comps)):
             assert res[i] == len(c), (i, hc, res[i], len(c))
             assert np.array_equal(dst[i, :a.size], a), (i, hc)
@@ -46,19 +52,19 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
     for extra in (0, 1, 100):
-        res, dst = emu.decode(comps, [a.size + extra for a in blocks], known=False, lane=lane)
+        res, dst = emu.decode(comps, [a.size + extra for a in blocks], known=False, **_mapping(lane))
         for i, (a, c) in enumerate(zip(blocks, comps)):
             assert res[i] == a.size, (i, extra, res[i])
             assert np.array_equal(dst[i, :a.size], a)
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
@@ -77,12 +83,12 @@ def test_decode_error_codes_match_oracle(oracle, lane):
             cases_u.append((cc, len(cc), a.size)); want_u.append(oracle.uncompress_unknown_raw(cc, len(cc), a.size)[0])
     # known-size: give the kernel a generous source length (zero padded) like the oracle wrapper does
     pad = [np.concatenate([c, np.zeros(max(o, 0) + 1024, np.uint8)]) for c, o in cases_k]
-    res, dst = emu.decode(pad, [o for _, o in cases_k], known=True, lane=lane)
+    res, dst = emu.decode(pad, [o for _, o in cases_k], known=True, **_mapping(lane))
     for i, w in enumerate(want_k):
         assert res[i] == w, ("known", i, res[i], w)
         assert (dst[i, max(cases_k[i][1], 0):] == 0xA5).all()
     padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c, _, _ in cases_u]
-    res, dst = emu.decode(padu, [mo for _, _, mo in cases_u], known=False, src_lens=[i for _, i, _ in cases_u], lane=lane)
+    res, dst = emu.decode(padu, [mo for _, _, mo in cases_u], known=False, src_lens=[i for _, i, _ in cases_u], **_mapping(lane))
     for i, w in enumerate(want_u):
         assert res[i] == w, ("unknown", i, res[i], w)
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
