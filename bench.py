@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--hc-blocks", type=int, default=1 << 14, help="blocks for the LZ4HC extra (0 = skip)")
-    ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged"], default="auto",
+    ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
@@ -297,7 +297,7 @@ def main():
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if args.decoder == "wave" or
                        (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
-                       else "lz4hip::decode_lane_kernel<true> (one lane per block)"),
+                       else "lz4hip::decode_chunked_kernel<true,256> (one lane per block, LDS output ring)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

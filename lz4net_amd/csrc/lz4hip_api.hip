@@ -8,6 +8,7 @@
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
 #include "lz4hip_decode_staged.hpp"
+#include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_synth.hpp"
@@ -159,7 +160,26 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     const char* force = getenv("LZ4HIP_DECODER");
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
     if (d.n_blocks < 4096 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
-    else if (force && (force[0] == 'l' || force[0] == 's')) { lane_filter = kAllBlocks; wave_filter = -1; }
+    else if (force && (force[0] == 'l' || force[0] == 's' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
+    const bool chunked = force ? force[0] == 'c' : true;
+    if (lane_filter >= 0 && chunked) {
+        // lane-per-block convergent state machine with a per-lane LDS output ring (lz4hip_decode_chunked.hpp)
+        const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
+        int ring = kChunkedRingBytes;
+        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
+        const unsigned lds = 64u * (unsigned)ring;
+#define LZ4HIP_LAUNCH_CHUNKED(R)                                                                                      \
+        do {                                                                                                          \
+            if (known) hipLaunchKernelGGL((decode_chunked_kernel<true, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);   \
+            else       hipLaunchKernelGGL((decode_chunked_kernel<false, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);  \
+        } while (0)
+        if (ring == 128) LZ4HIP_LAUNCH_CHUNKED(128);
+        else if (ring == 512) LZ4HIP_LAUNCH_CHUNKED(512);
+        else if (ring == 1024) LZ4HIP_LAUNCH_CHUNKED(1024);
+        else LZ4HIP_LAUNCH_CHUNKED(256);
+#undef LZ4HIP_LAUNCH_CHUNKED
+        lane_filter = -1;
+    }
     bool staged = kStagedByDefault;
     if (force && force[0] == 's') staged = true;
     if (force && force[0] == 'l') staged = false;

@@ -1,0 +1,237 @@
+// lz4hip_decode_chunked.hpp -- lane-per-block LZ4 decoder as a CONVERGENT state machine:
+// every loop iteration every lane (a) parses a sequence header if its previous copy is finished,
+// (b) produces at most 8 output bytes from whatever source its state says, (c) flushes one 16-byte
+// piece of finished output.  Same functions / return conventions as lz4hip_decode.hpp
+// (LZ4_uncompress, original/lz4.c:812-914; LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
+//
+// Why this shape (measured on MI355X, profiles/r01): with one lane per block the cost is not
+// arithmetic but (1) the number of vector-memory instructions -- a wavefront instruction whose 64 lanes
+// touch 64 different lines costs 3..30 CU-cycles PER LANE in the texture-address/L1 pipeline -- and
+// (2) divergence: a sequence-per-iteration loop executes the union of all lanes' paths
+// (~1300 instructions, ~40 vector-memory instructions per iteration in lz4hip_decode_staged.hpp).
+// Here the iteration body is one straight path of ~250 instructions with exactly three vector-memory
+// instructions (header-window prefetch, 8-byte source fetch for literal/far-match chunks, 16-byte
+// flush); everything else is LDS:
+//   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free), sequences are appended
+//     exactly, matches whose offset fits the ring are served from LDS, finished output leaves in 16-byte
+//     pieces that L2 merges into full lines;
+//   * the token, up to 11 literals, the offset and one match-length byte come out of ONE 16-byte
+//     window that was requested when the previous header was parsed.
+#pragma once
+#include "lz4hip_common.hpp"
+#include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
+
+namespace lz4hip {
+
+constexpr int kChunkedRingBytes = 256;     // per-lane output ring (LDS = 64 x this per wavefront)
+
+enum ChunkMode { kIdle = 0, kLitWin = 1, kLitGlobal = 2, kNear = 3, kPattern = 4, kFar = 5, kZeroOff = 6 };
+
+LZ4HIP_DEVICE uint32_t win_byte(uint64_t lo, uint64_t hi, int i)      // byte i (0..15) of a 16-byte window
+{
+    return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 255u);
+}
+LZ4HIP_DEVICE uint32_t win_u16(uint64_t lo, uint64_t hi, int i)       // little-endian u16 at byte i (0..14)
+{
+    const int sh = 8 * i;
+    const uint64_t v = sh == 0 ? lo : (sh < 64 ? ((lo >> sh) | (hi << (64 - sh))) : (hi >> (sh - 64)));
+    return (uint32_t)(v & 0xFFFFu);
+}
+
+template <bool KNOWN, int OUT_BYTES>
+LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8_t* __restrict__ src, int iend,
+                                       uint8_t* dst, int oend)
+{
+    if (!KNOWN && iend == 0) return 0;                               // lz4.c:946 returns -(0)
+    constexpr int OUT_Q = OUT_BYTES / 8;
+    constexpr int kNearMax = OUT_BYTES - 16;                         // largest offset served from the ring
+    uint64_t* out_q = (uint64_t*)lds + lane;                         // qword k of this lane at out_q[(k & (OUT_Q-1)) * 64]
+#define OUTQ(k) out_q[((k) & (OUT_Q - 1)) * 64]
+
+    // ---- per-lane state ----
+    int ip = 0;                  // position of the next header to parse
+    int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 16)
+    uint64_t tail = 0;           // qword containing op: low (op & 7) bytes valid, rest 0
+    uint64_t lo = 0, hi = 0;     // 16-byte window at `ip` (valid iff win_ok)
+    bool win_ok = false;
+    int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
+    int stride = 8;              // bytes per chunk (8, or a multiple of the offset for kPattern)
+    uint64_t cv = 0, cv2 = 0;    // kLitWin: literal bytes; kPattern: the period
+    int lit_src = 0;             // kLitGlobal: position of the next literal byte in src
+    int off = 0, ml = 0;         // pending / current match
+    bool match_pending = false;  // a match (off, ml) follows the current literal run
+    bool hdr_pending = false;    // the match header (offset, length) is still to be parsed at `ip` after the literals
+    uint32_t token = 0;
+    bool final_run = false;
+    int result = 0;
+
+    if (16 <= iend) {
+        const Vec16 w = load_v16(src);
+        lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); win_ok = true;
+    }
+
+    for (;;) {
+        // =========================== (a) header parsing ===========================
+        if (rem == 0 && mode == kIdle) {
+            if (!hdr_pending && !match_pending && !final_run) {
+                // ---- token + literal length at ip ----
+                token = win_ok ? (uint32_t)lo & 255u : (ip < iend ? src[ip] : 0u);
+                int ll = (int)(token >> 4);
+                const uint32_t mlc = token & 15u;
+                const int e = 3 + ll;                                // index of the first match-length byte
+                const uint32_t extb = (win_ok && ll <= 11) ? win_byte(lo, hi, e) : 255u;
+                // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
+                const bool fast = win_ok && ll <= 11 && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
+                int pos = ip + 1;                                    // position after token (+ length bytes)
+                if (ll == 15) {                                      // lz4.c:844 / :957-961
+                    uint32_t b = 255;
+                    if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
+                    else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
+                }
+                const int lit_end = op + ll;
+                const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
+                if (last) {                                          // lz4.c:851-858 / :965-975
+                    if (KNOWN) { if (lit_end != oend) return -pos; if (pos + ll > iend) return -pos; }
+                    else       { if (lit_end > oend) return -pos; if (pos + ll != iend) return -pos; }
+                    final_run = true;
+                    result = KNOWN ? pos + ll : lit_end;
+                    match_pending = false;
+                } else {
+                    if (KNOWN && pos + ll > iend) return -pos;       // never read literals past the source
+                }
+                // literal run: from the window when it is all there, else streamed from src
+                if (win_ok && ll <= 11 && pos == ip + 1) { mode = kLitWin; cv = (lo >> 8) | (hi << 56); cv2 = hi >> 8; }
+                else { mode = kLitGlobal; lit_src = pos; }
+                rem = ll; stride = 8;
+                if (!last) {
+                    if (fast) {                                      // offset + match length from the same window
+                        off = (int)win_u16(lo, hi, 1 + ll);
+                        const int p = ip + 3 + ll;                   // after the offset
+                        if (lit_end - off < 0) return -p;            // lz4.c:863 / :980
+                        ml = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
+                        ip = p + (mlc == 15u ? 1 : 0);
+                        if (lit_end + ml > oend - kLastLiterals) return -ip;    // lz4.c:893 / :1024
+                        match_pending = true;
+                    } else {
+                        hdr_pending = true;                          // parse offset/length at pos + ll after the literals
+                        ip = pos + ll;
+                    }
+                    // request the window for the next header now; it travels while this sequence is copied
+                    win_ok = ip + 16 <= iend;
+                    if (win_ok) { const Vec16 w = load_v16(src + ip); lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); }
+                }
+                if (rem == 0) mode = kIdle;                          // no literals: go on to the match below
+            }
+            if (rem == 0 && hdr_pending) {
+                // ---- offset + match length at ip (literal run longer than the token's window) ----
+                int p = ip;
+                off = win_ok ? (int)((uint32_t)lo & 0xFFFFu)
+                             : (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
+                p += 2;
+                if (op - off < 0) return -p;
+                ml = (int)(token & 15u);
+                if (ml == 15) {                                      // lz4.c:866 / :983-997
+                    if (KNOWN) {
+                        uint32_t b;
+                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
+                        ml += (int)b; p++;
+                    } else {
+                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
+                    }
+                }
+                ml += kMinMatch;
+                if (op + ml > oend - kLastLiterals) return -p;
+                ip = p;
+                hdr_pending = false; match_pending = true;
+                win_ok = ip + 16 <= iend;
+                if (win_ok) { const Vec16 w = load_v16(src + ip); lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); }
+            }
+            if (rem == 0 && match_pending) {
+                // ---- start the match copy ----
+                match_pending = false;
+                rem = ml; stride = 8;
+                if (off == 0) mode = kZeroOff;
+                else if (off < 8) {
+                    // periodic: build the period once; every chunk appends a multiple of `off` bytes
+                    const int k = (op - off) >> 3, s = ((op - off) & 7) * 8;
+                    const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
+                    uint64_t pat = (s ? (q0 >> s) | (q1 << (64 - s)) : q0) & ((1ull << (8 * off)) - 1ull);
+                    int sh = 8 * off;
+                    pat |= pat << sh; sh += sh;
+                    if (sh < 64) { pat |= pat << sh; sh += sh; }
+                    if (sh < 64) { pat |= pat << sh; }
+                    cv = pat;
+                    stride = (int)((0x76586880u >> (4 * off)) & 15u);   // off 1..7 -> 8,8,6,8,5,6,7
+                    mode = kPattern;
+                } else mode = off <= kNearMax ? kNear : kFar;
+            }
+            if (rem == 0 && final_run && mode != kIdle) mode = kIdle;
+        }
+
+        // =========================== (b) one chunk ===========================
+        if (rem > 0) {
+            const int n = rem < stride ? rem : stride;
+            uint64_t v;
+            if (mode == kLitWin) { v = cv; cv = cv2; }
+            else if (mode == kPattern) v = cv;
+            else if (mode == kNear) {
+                const int sp = op - off, k = sp >> 3, s = (sp & 7) * 8;
+                const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
+                v = s ? (q0 >> s) | (q1 << (64 - s)) : q0;
+            } else if (mode == kFar) {
+                v = load_u64(dst + (op - off));                     // older than the ring: already flushed
+            } else if (mode == kLitGlobal) {
+                if (lit_src + 8 <= iend) v = load_u64(src + lit_src);
+                else { v = 0; for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b); }
+                lit_src += n;
+            } else {                                                 // kZeroOff: out[i] = out[i], keep what dst holds
+                v = 0; for (int b = 0; b < n; b++) v |= (uint64_t)dst[op + b] << (8 * b);
+            }
+            // append the low n bytes of v
+            if (n < 8) v &= (1ull << (8 * n)) - 1ull;
+            const int k = op >> 3, s = (op & 7) * 8;
+            const uint64_t cur = tail | (v << s);
+            OUTQ(k) = cur;
+            if (s + 8 * n >= 64) {
+                tail = s ? (v >> (64 - s)) : 0ull;
+                if (s + 8 * n > 64) OUTQ(k + 1) = tail;
+            } else tail = cur;
+            op += n; rem -= n;
+            if (rem == 0) mode = kIdle;
+        }
+
+        // =========================== (c) flush one finished 16-byte piece ===========================
+        if (op - flushed >= 16) {
+            const uint64_t a = OUTQ(flushed >> 3), b2 = OUTQ((flushed >> 3) + 1);
+            const Vec16 v16 = { { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32) } };
+            store_v16(dst + flushed, v16);
+            flushed += 16;
+        }
+
+        if (final_run && rem == 0 && mode == kIdle && !match_pending && !hdr_pending) {
+            // ---- end of block: write out the last (< 32) bytes exactly ----
+            while (op - flushed >= 8) { store_u64(dst + flushed, OUTQ(flushed >> 3)); flushed += 8; }
+            if (flushed < op) {
+                const uint64_t q = OUTQ(flushed >> 3);
+                for (int b = 0; flushed + b < op; b++) dst[flushed + b] = (uint8_t)(q >> (8 * b));
+            }
+            return result;
+        }
+    }
+#undef OUTQ
+}
+
+// One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.  Dynamic LDS: 64 * OUT_BYTES.
+template <bool KNOWN, int OUT_BYTES>
+__global__ void __launch_bounds__(64) decode_chunked_kernel(Batch b, int filter)
+{
+    LZ4HIP_DYN_LDS(lds);
+    const int lane = (int)threadIdx.x;
+    const int64_t blk = (int64_t)blockIdx.x * 64 + lane;
+    if (blk >= b.n_blocks) return;
+    const int src_len = batch_src_len(b, blk), out_size = batch_dst_cap(b, blk);
+    if (!block_selected(filter, src_len, out_size)) return;
+    b.result[blk] = chunked_decode_block<KNOWN, OUT_BYTES>(lds, lane, batch_src(b, blk), src_len, batch_dst(b, blk), out_size);
+}
+
+}  // namespace lz4hip

@@ -7,6 +7,7 @@
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
 #include "lz4hip_decode_staged.hpp"
+#include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
@@ -58,6 +59,20 @@ void emu_decode_staged(int known, const uint8_t* src, int64_t src_stride, const 
     } else {
         if (known) simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<true, 512>(b, filter); });
         else       simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<false, 512>(b, filter); });
+    }
+}
+
+void emu_decode_chunked(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (ring == 128) {
+        if (known) simt::launch(grid, block, 64 * 128, [=] { decode_chunked_kernel<true, 128>(b, filter); });
+        else       simt::launch(grid, block, 64 * 128, [=] { decode_chunked_kernel<false, 128>(b, filter); });
+    } else {
+        if (known) simt::launch(grid, block, 64 * 256, [=] { decode_chunked_kernel<true, 256>(b, filter); });
+        else       simt::launch(grid, block, 64 * 256, [=] { decode_chunked_kernel<false, 256>(b, filter); });
     }
 }
 

@@ -30,7 +30,7 @@ def test_device_generators_match_cpu_twins(torch_cuda, oracle):
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
 @pytest.mark.parametrize("hc", [False, True])
-@pytest.mark.parametrize("decoder", ["wave", "lane", "staged"])
+@pytest.mark.parametrize("decoder", ["wave", "lane", "staged", "chunked"])
 def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc, decoder, monkeypatch):
     torch = torch_cuda
     from lz4net_amd import batch

@@ -87,7 +87,7 @@ def test_limited_output(gpu, oracle):
                 assert (dst[i, caps[i]:] == 0xA5).all(), (i, hc, delta, "wrote past the capacity")
 
 
-@pytest.fixture(params=["wave", "lane", "staged"])
+@pytest.fixture(params=["wave", "lane", "staged", "chunked"])
 def decoder(request):
     """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane.hpp)."""
     os.environ["LZ4HIP_DECODER"] = request.param

@@ -13,7 +13,7 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 def _mapping(m):
     if isinstance(m, str):
-        return dict(staged=int(m[6:]))
+        return dict(chunked=int(m[7:])) if m.startswith("chunked") else dict(staged=int(m[6:]))
     return dict(lane=m)
 
 
@@ -31,7 +31,8 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
+                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
 def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
@@ -52,7 +53,8 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
+                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -64,7 +66,8 @@ def test_decode_unknown_size(oracle, lane):
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512"], ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512"])
+@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
+                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
