@@ -15,15 +15,16 @@
 //   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free), sequences are appended
 //     exactly, matches whose offset fits the ring are served from LDS, finished output leaves in 16-byte
 //     pieces that L2 merges into full lines;
-//   * the token, up to 11 literals, the offset and one match-length byte come out of ONE 16-byte
-//     window that was requested when the previous header was parsed.
+//   * the token, up to 11 literals, the offset and one match-length byte come out of a 32-byte register
+//     window over the compressed stream that slides 16 bytes at a time: one 16-byte load serves ~3
+//     short sequences and is requested at least one header before it is needed.
 #pragma once
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
 
 namespace lz4hip {
 
-constexpr int kChunkedRingBytes = 256;     // per-lane output ring (LDS = 64 x this per wavefront)
+constexpr int kChunkedRingBytes = 128;     // per-lane output ring (LDS = 64 x this per wavefront)
 
 enum ChunkMode { kIdle = 0, kLitWin = 1, kLitGlobal = 2, kNear = 3, kPattern = 4, kFar = 5, kZeroOff = 6 };
 
@@ -52,8 +53,10 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     int ip = 0;                  // position of the next header to parse
     int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 16)
     uint64_t tail = 0;           // qword containing op: low (op & 7) bytes valid, rest 0
-    uint64_t lo = 0, hi = 0;     // 16-byte window at `ip` (valid iff win_ok)
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
+    int win_pos = 0;
     bool win_ok = false;
+    uint64_t lo = 0, hi = 0;     // the 16 bytes at `ip`, extracted from the window
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
     int stride = 8;              // bytes per chunk (8, or a multiple of the offset for kPattern)
     uint64_t cv = 0, cv2 = 0;    // kLitWin: literal bytes; kPattern: the period
@@ -63,18 +66,46 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     bool hdr_pending = false;    // the match header (offset, length) is still to be parsed at `ip` after the literals
     uint32_t token = 0;
     bool final_run = false;
+    bool half = false;           // kFar / kLitGlobal: cv2 holds the next 8 source bytes of a 16-byte fetch
     int result = 0;
 
-    if (16 <= iend) {
-        const Vec16 w = load_v16(src);
-        lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); win_ok = true;
-    }
+    // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
+    // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes, which
+    // are not needed before the header after next.
+#define SLIDE_WINDOW(pos)                                                                               \
+    do {                                                                                                \
+        const int d_ = (pos) - win_pos;                                                                 \
+        if (win_ok && d_ >= 0 && d_ < 16) {                                                             \
+        } else if (win_ok && d_ >= 16 && d_ < 32 && win_pos + 48 <= iend) {                             \
+            w0 = w2; w1 = w3; win_pos += 16;                                                            \
+            const Vec16 n_ = load_v16(src + win_pos + 16);                                              \
+            w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
+        } else if ((pos) + 32 <= iend) {                                                                \
+            win_pos = (pos); win_ok = true;                                                             \
+            const Vec16 m_ = load_v16(src + win_pos), n_ = load_v16(src + win_pos + 16);                \
+            w0 = m_.w[0] | ((uint64_t)m_.w[1] << 32); w1 = m_.w[2] | ((uint64_t)m_.w[3] << 32);        \
+            w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
+        } else win_ok = false;                                                                          \
+    } while (0)
+    // (lo, hi) = the 16 bytes at pos; requires win_ok and 0 <= pos - win_pos < 16
+#define EXTRACT_WINDOW(pos)                                                                             \
+    do {                                                                                                \
+        const int d_ = (pos) - win_pos;                                                                 \
+        const bool up_ = d_ >= 8;                                                                       \
+        const uint64_t x0_ = up_ ? w1 : w0, x1_ = up_ ? w2 : w1, x2_ = up_ ? w3 : w2;                   \
+        const int s_ = 8 * (d_ & 7);                                                                    \
+        lo = s_ ? (x0_ >> s_) | (x1_ << (64 - s_)) : x0_;                                               \
+        hi = s_ ? (x1_ >> s_) | (x2_ << (64 - s_)) : x1_;                                               \
+    } while (0)
+
+    SLIDE_WINDOW(0);
 
     for (;;) {
         // =========================== (a) header parsing ===========================
         if (rem == 0 && mode == kIdle) {
             if (!hdr_pending && !match_pending && !final_run) {
                 // ---- token + literal length at ip ----
+                if (win_ok) EXTRACT_WINDOW(ip);
                 token = win_ok ? (uint32_t)lo & 255u : (ip < iend ? src[ip] : 0u);
                 int ll = (int)(token >> 4);
                 const uint32_t mlc = token & 15u;
@@ -116,15 +147,15 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                         hdr_pending = true;                          // parse offset/length at pos + ll after the literals
                         ip = pos + ll;
                     }
-                    // request the window for the next header now; it travels while this sequence is copied
-                    win_ok = ip + 16 <= iend;
-                    if (win_ok) { const Vec16 w = load_v16(src + ip); lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); }
+                    // make sure the window covers the next header; a needed load travels while this sequence is copied
+                    SLIDE_WINDOW(ip);
                 }
                 if (rem == 0) mode = kIdle;                          // no literals: go on to the match below
             }
             if (rem == 0 && hdr_pending) {
                 // ---- offset + match length at ip (literal run longer than the token's window) ----
                 int p = ip;
+                if (win_ok) EXTRACT_WINDOW(ip);
                 off = win_ok ? (int)((uint32_t)lo & 0xFFFFu)
                              : (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
                 p += 2;
@@ -143,8 +174,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 if (op + ml > oend - kLastLiterals) return -p;
                 ip = p;
                 hdr_pending = false; match_pending = true;
-                win_ok = ip + 16 <= iend;
-                if (win_ok) { const Vec16 w = load_v16(src + ip); lo = w.w[0] | ((uint64_t)w.w[1] << 32); hi = w.w[2] | ((uint64_t)w.w[3] << 32); }
+                SLIDE_WINDOW(ip);
             }
             if (rem == 0 && match_pending) {
                 // ---- start the match copy ----
@@ -179,9 +209,18 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
                 v = s ? (q0 >> s) | (q1 << (64 - s)) : q0;
             } else if (mode == kFar) {
-                v = load_u64(dst + (op - off));                     // older than the ring: already flushed
+                // older than the ring: already flushed.  Fetch 16 bytes, use them over two chunks.
+                if (half) { v = cv2; half = false; }
+                else if (rem > 8) {
+                    const Vec16 w = load_v16(dst + (op - off));
+                    v = w.w[0] | ((uint64_t)w.w[1] << 32); cv2 = w.w[2] | ((uint64_t)w.w[3] << 32); half = true;
+                } else v = load_u64(dst + (op - off));
             } else if (mode == kLitGlobal) {
-                if (lit_src + 8 <= iend) v = load_u64(src + lit_src);
+                if (half) { v = cv2; half = false; }
+                else if (rem > 8 && lit_src + 16 <= iend) {
+                    const Vec16 w = load_v16(src + lit_src);
+                    v = w.w[0] | ((uint64_t)w.w[1] << 32); cv2 = w.w[2] | ((uint64_t)w.w[3] << 32); half = true;
+                } else if (lit_src + 8 <= iend) v = load_u64(src + lit_src);
                 else { v = 0; for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b); }
                 lit_src += n;
             } else {                                                 // kZeroOff: out[i] = out[i], keep what dst holds
@@ -197,7 +236,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 if (s + 8 * n > 64) OUTQ(k + 1) = tail;
             } else tail = cur;
             op += n; rem -= n;
-            if (rem == 0) mode = kIdle;
+            if (rem == 0) { mode = kIdle; half = false; }
         }
 
         // =========================== (c) flush one finished 16-byte piece ===========================
@@ -219,6 +258,8 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         }
     }
 #undef OUTQ
+#undef SLIDE_WINDOW
+#undef EXTRACT_WINDOW
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.  Dynamic LDS: 64 * OUT_BYTES.
