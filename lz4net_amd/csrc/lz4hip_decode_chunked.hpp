@@ -1,23 +1,27 @@
 // lz4hip_decode_chunked.hpp -- lane-per-block LZ4 decoder as a CONVERGENT state machine:
-// every loop iteration every lane (a) parses a sequence header if its previous copy is finished,
-// (b) produces at most 8 output bytes from whatever source its state says, (c) flushes one 16-byte
-// piece of finished output.  Same functions / return conventions as lz4hip_decode.hpp
-// (LZ4_uncompress, original/lz4.c:812-914; LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
+// every loop iteration every lane (b) produces at most 8 output bytes from whatever source its state
+// says, (a) parses a sequence header if its copy is finished, (d) requests the next 16 source bytes if
+// it is copying from global memory, (c) flushes one 16-byte piece of finished output.
+// Same functions / return conventions as lz4hip_decode.hpp (LZ4_uncompress, original/lz4.c:812-914;
+// LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
 //
 // Why this shape (measured on MI355X, profiles/r01): with one lane per block the cost is not
-// arithmetic but (1) the number of vector-memory instructions -- a wavefront instruction whose 64 lanes
-// touch 64 different lines costs 3..30 CU-cycles PER LANE in the texture-address/L1 pipeline -- and
-// (2) divergence: a sequence-per-iteration loop executes the union of all lanes' paths
-// (~1300 instructions, ~40 vector-memory instructions per iteration in lz4hip_decode_staged.hpp).
-// Here the iteration body is one straight path of ~250 instructions with exactly three vector-memory
-// instructions (header-window prefetch, 8-byte source fetch for literal/far-match chunks, 16-byte
-// flush); everything else is LDS:
-//   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free), sequences are appended
-//     exactly, matches whose offset fits the ring are served from LDS, finished output leaves in 16-byte
-//     pieces that L2 merges into full lines;
-//   * the token, up to 11 literals, the offset and one match-length byte come out of a 32-byte register
-//     window over the compressed stream that slides 16 bytes at a time: one 16-byte load serves ~3
-//     short sequences and is requested at least one header before it is needed.
+// arithmetic but (1) vector-memory instructions -- a wavefront instruction whose 64 lanes touch 64
+// different lines costs 3..30 CU-cycles PER LANE in the texture-address/L1 pipeline, (2) divergence --
+// a sequence-per-iteration loop executes the union of all lanes' paths (~1300 instructions and ~40
+// vector-memory instructions per iteration in lz4hip_decode_staged.hpp), and (3) any load that is
+// consumed in the iteration that issues it stalls the whole wavefront for a memory round trip, and
+// with 64 lanes "some lane needs one" is true every iteration.  So:
+//   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free); sequences are
+//     appended exactly; matches whose offset fits the ring are served from LDS; finished output leaves
+//     in 16-byte pieces that L2 merges into full lines;
+//   * every header byte (token, one literal-length byte, <= 11 literals, offset, one match-length byte)
+//     comes out of a 32-byte register window over the compressed stream that slides 16 bytes at a time;
+//     its loads are requested at least one header before they are needed;
+//   * far matches and long literal runs stream through a 16-byte register pair that is requested at
+//     the END of an iteration and consumed in the next ones;
+//   * anything else (length runs of 0xFF bytes, the last bytes of the input, offset 0) takes a slow
+//     byte-wise path that is correct but rare.
 #pragma once
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
@@ -26,18 +30,8 @@ namespace lz4hip {
 
 constexpr int kChunkedRingBytes = 128;     // per-lane output ring (LDS = 64 x this per wavefront)
 
-enum ChunkMode { kIdle = 0, kLitWin = 1, kLitGlobal = 2, kNear = 3, kPattern = 4, kFar = 5, kZeroOff = 6 };
-
-LZ4HIP_DEVICE uint32_t win_byte(uint64_t lo, uint64_t hi, int i)      // byte i (0..15) of a 16-byte window
-{
-    return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 255u);
-}
-LZ4HIP_DEVICE uint32_t win_u16(uint64_t lo, uint64_t hi, int i)       // little-endian u16 at byte i (0..14)
-{
-    const int sh = 8 * i;
-    const uint64_t v = sh == 0 ? lo : (sh < 64 ? ((lo >> sh) | (hi << (64 - sh))) : (hi >> (sh - 64)));
-    return (uint32_t)(v & 0xFFFFu);
-}
+// what the next chunk of a lane's current copy is made from
+enum ChunkMode { kIdle = 0, kReg = 1, kNear = 2, kGlobal = 3, kSlowLit = 4, kZeroOff = 5 };
 
 template <bool KNOWN, int OUT_BYTES>
 LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8_t* __restrict__ src, int iend,
@@ -56,22 +50,22 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
     int win_pos = 0;
     bool win_ok = false;
-    uint64_t lo = 0, hi = 0;     // the 16 bytes at `ip`, extracted from the window
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
-    int stride = 8;              // bytes per chunk (8, or a multiple of the offset for kPattern)
-    uint64_t cv = 0, cv2 = 0;    // kLitWin: literal bytes; kPattern: the period
-    int lit_src = 0;             // kLitGlobal: position of the next literal byte in src
+    int stride = 8;              // bytes per chunk (8, or a multiple of the offset for a periodic match)
+    uint64_t cv = 0, cv2 = 0;    // kReg: this chunk / next chunk (literals from the window, or the period)
+    uint64_t g0 = 0, g1 = 0;     // kGlobal: fetched source bytes
+    int gcount = 0;              // kGlobal: valid 8-byte halves in (g0, g1)
+    const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
+    int lit_src = 0;             // kSlowLit: position of the next literal byte in src
     int off = 0, ml = 0;         // pending / current match
     bool match_pending = false;  // a match (off, ml) follows the current literal run
-    bool hdr_pending = false;    // the match header (offset, length) is still to be parsed at `ip` after the literals
+    bool hdr_pending = false;    // offset + match length are still to be parsed at `ip` after the literals
     uint32_t token = 0;
     bool final_run = false;
-    bool half = false;           // kFar / kLitGlobal: cv2 holds the next 8 source bytes of a 16-byte fetch
     int result = 0;
 
     // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
-    // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes, which
-    // are not needed before the header after next.
+    // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes.
 #define SLIDE_WINDOW(pos)                                                                               \
     do {                                                                                                \
         const int d_ = (pos) - win_pos;                                                                 \
@@ -87,146 +81,26 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
         } else win_ok = false;                                                                          \
     } while (0)
-    // (lo, hi) = the 16 bytes at pos; requires win_ok and 0 <= pos - win_pos < 16
-#define EXTRACT_WINDOW(pos)                                                                             \
-    do {                                                                                                \
-        const int d_ = (pos) - win_pos;                                                                 \
-        const bool up_ = d_ >= 8;                                                                       \
-        const uint64_t x0_ = up_ ? w1 : w0, x1_ = up_ ? w2 : w1, x2_ = up_ ? w3 : w2;                   \
-        const int s_ = 8 * (d_ & 7);                                                                    \
-        lo = s_ ? (x0_ >> s_) | (x1_ << (64 - s_)) : x0_;                                               \
-        hi = s_ ? (x1_ >> s_) | (x2_ << (64 - s_)) : x1_;                                               \
-    } while (0)
 
     SLIDE_WINDOW(0);
 
     for (;;) {
-        // =========================== (a) header parsing ===========================
-        if (rem == 0 && mode == kIdle) {
-            if (!hdr_pending && !match_pending && !final_run) {
-                // ---- token + literal length at ip ----
-                if (win_ok) EXTRACT_WINDOW(ip);
-                token = win_ok ? (uint32_t)lo & 255u : (ip < iend ? src[ip] : 0u);
-                int ll = (int)(token >> 4);
-                const uint32_t mlc = token & 15u;
-                const int e = 3 + ll;                                // index of the first match-length byte
-                const uint32_t extb = (win_ok && ll <= 11) ? win_byte(lo, hi, e) : 255u;
-                // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
-                const bool fast = win_ok && ll <= 11 && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
-                int pos = ip + 1;                                    // position after token (+ length bytes)
-                if (ll == 15) {                                      // lz4.c:844 / :957-961
-                    uint32_t b = 255;
-                    if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
-                    else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
-                }
-                const int lit_end = op + ll;
-                const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
-                if (last) {                                          // lz4.c:851-858 / :965-975
-                    if (KNOWN) { if (lit_end != oend) return -pos; if (pos + ll > iend) return -pos; }
-                    else       { if (lit_end > oend) return -pos; if (pos + ll != iend) return -pos; }
-                    final_run = true;
-                    result = KNOWN ? pos + ll : lit_end;
-                    match_pending = false;
-                } else {
-                    if (KNOWN && pos + ll > iend) return -pos;       // never read literals past the source
-                }
-                // literal run: from the window when it is all there, else streamed from src
-                if (win_ok && ll <= 11 && pos == ip + 1) { mode = kLitWin; cv = (lo >> 8) | (hi << 56); cv2 = hi >> 8; }
-                else { mode = kLitGlobal; lit_src = pos; }
-                rem = ll; stride = 8;
-                if (!last) {
-                    if (fast) {                                      // offset + match length from the same window
-                        off = (int)win_u16(lo, hi, 1 + ll);
-                        const int p = ip + 3 + ll;                   // after the offset
-                        if (lit_end - off < 0) return -p;            // lz4.c:863 / :980
-                        ml = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
-                        ip = p + (mlc == 15u ? 1 : 0);
-                        if (lit_end + ml > oend - kLastLiterals) return -ip;    // lz4.c:893 / :1024
-                        match_pending = true;
-                    } else {
-                        hdr_pending = true;                          // parse offset/length at pos + ll after the literals
-                        ip = pos + ll;
-                    }
-                    // make sure the window covers the next header; a needed load travels while this sequence is copied
-                    SLIDE_WINDOW(ip);
-                }
-                if (rem == 0) mode = kIdle;                          // no literals: go on to the match below
-            }
-            if (rem == 0 && hdr_pending) {
-                // ---- offset + match length at ip (literal run longer than the token's window) ----
-                int p = ip;
-                if (win_ok) EXTRACT_WINDOW(ip);
-                off = win_ok ? (int)((uint32_t)lo & 0xFFFFu)
-                             : (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
-                p += 2;
-                if (op - off < 0) return -p;
-                ml = (int)(token & 15u);
-                if (ml == 15) {                                      // lz4.c:866 / :983-997
-                    if (KNOWN) {
-                        uint32_t b;
-                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
-                        ml += (int)b; p++;
-                    } else {
-                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
-                    }
-                }
-                ml += kMinMatch;
-                if (op + ml > oend - kLastLiterals) return -p;
-                ip = p;
-                hdr_pending = false; match_pending = true;
-                SLIDE_WINDOW(ip);
-            }
-            if (rem == 0 && match_pending) {
-                // ---- start the match copy ----
-                match_pending = false;
-                rem = ml; stride = 8;
-                if (off == 0) mode = kZeroOff;
-                else if (off < 8) {
-                    // periodic: build the period once; every chunk appends a multiple of `off` bytes
-                    const int k = (op - off) >> 3, s = ((op - off) & 7) * 8;
-                    const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
-                    uint64_t pat = (s ? (q0 >> s) | (q1 << (64 - s)) : q0) & ((1ull << (8 * off)) - 1ull);
-                    int sh = 8 * off;
-                    pat |= pat << sh; sh += sh;
-                    if (sh < 64) { pat |= pat << sh; sh += sh; }
-                    if (sh < 64) { pat |= pat << sh; }
-                    cv = pat;
-                    stride = (int)((0x76586880u >> (4 * off)) & 15u);   // off 1..7 -> 8,8,6,8,5,6,7
-                    mode = kPattern;
-                } else mode = off <= kNearMax ? kNear : kFar;
-            }
-            if (rem == 0 && final_run && mode != kIdle) mode = kIdle;
-        }
-
-        // =========================== (b) one chunk ===========================
-        if (rem > 0) {
+        // =========================== (b) one chunk of the current copy ===========================
+        if (rem > 0 && !(mode == kGlobal && gcount == 0)) {
             const int n = rem < stride ? rem : stride;
             uint64_t v;
-            if (mode == kLitWin) { v = cv; cv = cv2; }
-            else if (mode == kPattern) v = cv;
+            if (mode == kReg) { v = cv; cv = cv2; }
             else if (mode == kNear) {
                 const int sp = op - off, k = sp >> 3, s = (sp & 7) * 8;
                 const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
                 v = s ? (q0 >> s) | (q1 << (64 - s)) : q0;
-            } else if (mode == kFar) {
-                // older than the ring: already flushed.  Fetch 16 bytes, use them over two chunks.
-                if (half) { v = cv2; half = false; }
-                else if (rem > 8) {
-                    const Vec16 w = load_v16(dst + (op - off));
-                    v = w.w[0] | ((uint64_t)w.w[1] << 32); cv2 = w.w[2] | ((uint64_t)w.w[3] << 32); half = true;
-                } else v = load_u64(dst + (op - off));
-            } else if (mode == kLitGlobal) {
-                if (half) { v = cv2; half = false; }
-                else if (rem > 8 && lit_src + 16 <= iend) {
-                    const Vec16 w = load_v16(src + lit_src);
-                    v = w.w[0] | ((uint64_t)w.w[1] << 32); cv2 = w.w[2] | ((uint64_t)w.w[3] << 32); half = true;
-                } else if (lit_src + 8 <= iend) v = load_u64(src + lit_src);
-                else { v = 0; for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b); }
+            } else if (mode == kGlobal) { v = g0; g0 = g1; gcount--; }
+            else if (mode == kSlowLit) {
+                v = 0; for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b);
                 lit_src += n;
             } else {                                                 // kZeroOff: out[i] = out[i], keep what dst holds
                 v = 0; for (int b = 0; b < n; b++) v |= (uint64_t)dst[op + b] << (8 * b);
             }
-            // append the low n bytes of v
             if (n < 8) v &= (1ull << (8 * n)) - 1ull;
             const int k = op >> 3, s = (op & 7) * 8;
             const uint64_t cur = tail | (v << s);
@@ -236,7 +110,143 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 if (s + 8 * n > 64) OUTQ(k + 1) = tail;
             } else tail = cur;
             op += n; rem -= n;
-            if (rem == 0) { mode = kIdle; half = false; }
+            if (rem == 0) mode = kIdle;
+        }
+
+        // =========================== (a) header parsing ===========================
+        if (rem == 0) {
+            if (!hdr_pending && !match_pending && !final_run) {
+                // ---- token [+ literal length] at ip ----
+                uint64_t lo = 0, hi = 0;
+                if (win_ok) {
+                    const int d = ip - win_pos;
+                    const bool up = d >= 8;
+                    const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1, x2 = up ? w3 : w2;
+                    const int s = 8 * (d & 7);
+                    lo = s ? (x0 >> s) | (x1 << (64 - s)) : x0;
+                    hi = s ? (x1 >> s) | (x2 << (64 - s)) : x1;
+                }
+                token = win_ok ? (uint32_t)lo & 255u : (ip < iend ? src[ip] : 0u);
+                int ll = (int)(token >> 4);
+                const uint32_t mlc = token & 15u;
+                int pos = ip + 1;                                    // position after token (+ literal-length bytes)
+                if (ll == 15) {                                      // lz4.c:844 / :957-961
+                    const uint32_t b1 = (uint32_t)(lo >> 8) & 255u;
+                    if (win_ok && b1 != 255u) { ll += (int)b1; pos++; }           // one length byte, from the window
+                    else {
+                        uint32_t b = 255;
+                        if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
+                        else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
+                    }
+                }
+                const bool in_win = win_ok && ll <= 11;              // literals, offset and first match-length byte are in (lo, hi)
+                const int lit_end = op + ll;
+                const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
+                if (last) {                                          // lz4.c:851-858 / :965-975
+                    if (KNOWN) { if (lit_end != oend) return -pos; if (pos + ll > iend) return -pos; }
+                    else       { if (lit_end > oend) return -pos; if (pos + ll != iend) return -pos; }
+                    final_run = true;
+                    result = KNOWN ? pos + ll : lit_end;
+                } else {
+                    if (KNOWN && pos + ll > iend) return -pos;       // never read literals past the source
+                }
+                // ---- where the literals come from ----
+                rem = ll; stride = 8;
+                if (in_win) { mode = kReg; cv = (lo >> 8) | (hi << 56); cv2 = hi >> 8; }
+                else if (pos + ll + 16 <= iend) { mode = kGlobal; gptr = src + pos; gcount = 0; }
+                else { mode = kSlowLit; lit_src = pos; }
+                if (!last) {
+                    bool fast = false;
+                    if (in_win) {
+                        // offset + match length from the same 16 bytes
+                        const int e = 3 + ll;                        // index of the first match-length byte (<= 14)
+                        const uint32_t extb = (uint32_t)((e < 8 ? lo >> (8 * e) : hi >> (8 * (e - 8))) & 255u);
+                        // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
+                        fast = mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1)));
+                        if (fast) {
+                            const int sh = 8 * (1 + ll);             // 8 .. 96
+                            const uint64_t v = sh < 64 ? ((lo >> sh) | (hi << (64 - sh))) : (hi >> (sh - 64));
+                            off = (int)(v & 0xFFFFu);
+                            const int p = ip + 3 + ll;               // after the offset
+                            if (lit_end - off < 0) return -p;        // lz4.c:863 / :980
+                            ml = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
+                            ip = p + (mlc == 15u ? 1 : 0);
+                            if (lit_end + ml > oend - kLastLiterals) return -ip;    // lz4.c:893 / :1024
+                            match_pending = true;
+                        }
+                    }
+                    if (!fast) { hdr_pending = true; ip = pos + ll; }   // offset/length are parsed after the literals
+                    SLIDE_WINDOW(ip);                                // a needed load travels while this sequence is copied
+                }
+                if (rem == 0) mode = kIdle;
+            }
+            if (rem == 0 && hdr_pending) {
+                // ---- offset + match length at ip (after a literal run that did not fit the token's window) ----
+                int p = ip + 2;
+                bool have = false;
+                if (win_ok) {
+                    const int d = ip - win_pos;
+                    const bool up = d >= 8;
+                    const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1;
+                    const int s = 8 * (d & 7);
+                    const uint64_t lo = s ? (x0 >> s) | (x1 << (64 - s)) : x0;
+                    off = (int)((uint32_t)lo & 0xFFFFu);
+                    ml = (int)(token & 15u);
+                    const uint32_t b = (uint32_t)(lo >> 16) & 255u;
+                    if (ml != 15) have = true;
+                    else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
+                }
+                if (!have) {                                         // slow: byte-wise, lz4.c:862-866 / :979-997
+                    p = ip;
+                    off = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
+                    p += 2;
+                    ml = (int)(token & 15u);
+                    if (ml == 15) {
+                        if (KNOWN) {
+                            uint32_t b;
+                            while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
+                            ml += (int)b; p++;
+                        } else {
+                            while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
+                        }
+                    }
+                }
+                if (op - off < 0) return -(ip + 2);
+                ml += kMinMatch;
+                if (op + ml > oend - kLastLiterals) return -p;
+                ip = p;
+                hdr_pending = false; match_pending = true;
+                SLIDE_WINDOW(ip);
+            }
+            if (rem == 0 && match_pending) {
+                // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
+                match_pending = false;
+                rem = ml; stride = 8;
+                if (off == 0) mode = kZeroOff;
+                else if (off < 8) {
+                    // periodic: build the period once; every chunk appends a multiple of `off` bytes
+                    const int sp = op - off, k = sp >> 3, s = (sp & 7) * 8;
+                    const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
+                    uint64_t pat = (s ? (q0 >> s) | (q1 << (64 - s)) : q0) & ((1ull << (8 * off)) - 1ull);
+                    int sh = 8 * off;
+                    pat |= pat << sh; sh += sh;
+                    if (sh < 64) { pat |= pat << sh; sh += sh; }
+                    if (sh < 64) { pat |= pat << sh; }
+                    cv = pat; cv2 = pat;
+                    stride = (int)((0x76586880u >> (4 * off)) & 15u);   // off 1..7 -> 8,8,6,8,5,6,7
+                    mode = kReg;
+                } else if (off <= kNearMax) mode = kNear;
+                else { mode = kGlobal; gptr = dst + (op - off); gcount = 0; }   // older than the ring: already flushed
+            }
+        }
+
+        // =========================== (d) request the next 16 source bytes ===========================
+        // (consumed from the next iteration on; a far source lies > OUT_BYTES - 16 behind op, the fetch
+        //  reads at most 16 bytes past the chunk start, and everything up to op - 23 has been flushed)
+        if (mode == kGlobal && gcount == 0 && rem > 0) {
+            const Vec16 w = load_v16(gptr);
+            g0 = w.w[0] | ((uint64_t)w.w[1] << 32); g1 = w.w[2] | ((uint64_t)w.w[3] << 32);
+            gcount = 2; gptr += 16;
         }
 
         // =========================== (c) flush one finished 16-byte piece ===========================
@@ -247,7 +257,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             flushed += 16;
         }
 
-        if (final_run && rem == 0 && mode == kIdle && !match_pending && !hdr_pending) {
+        if (final_run && rem == 0) {
             // ---- end of block: write out the last (< 32) bytes exactly ----
             while (op - flushed >= 8) { store_u64(dst + flushed, OUTQ(flushed >> 3)); flushed += 8; }
             if (flushed < op) {
@@ -259,7 +269,6 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     }
 #undef OUTQ
 #undef SLIDE_WINDOW
-#undef EXTRACT_WINDOW
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.  Dynamic LDS: 64 * OUT_BYTES.
