@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--hc-blocks", type=int, default=1 << 14, help="blocks for the LZ4HC extra (0 = skip)")
     ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
+    ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
 
@@ -171,6 +172,8 @@ def main():
     seed = args.seed
     if args.decoder != "auto":
         os.environ["LZ4HIP_DECODER"] = args.decoder
+    if args.encoder != "auto":
+        os.environ["LZ4HIP_ENCODER"] = args.encoder
     wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world, dst_pad=args.dst_pad)
     for _ in range(max(args.warmup, 0)):
         wl.decode_step()

@@ -10,6 +10,7 @@
 #include "lz4hip_decode_staged.hpp"
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
+#include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_synth.hpp"
 
@@ -99,14 +100,14 @@ struct HcWorkspace {
     void* p = nullptr; size_t cap = 0; int dev = -1;
     std::mutex mu;
 };
-HcWorkspace g_hc_ws[64];
+HcWorkspace g_hc_ws[64], g_fast_ws[64];
 
-int hc_workspace(size_t bytes, void** out)
+int workspace(HcWorkspace* pool, size_t bytes, void** out)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
-    HcWorkspace& w = g_hc_ws[dev];
+    HcWorkspace& w = pool[dev];
     std::lock_guard<std::mutex> lock(w.mu);
     if (w.cap < bytes) {
         if (w.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
@@ -122,7 +123,30 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
     if (mode == LZ4HIP_MODE_FAST) {
-        hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d);
+        // Two mappings (lz4hip_encode.hpp: one wavefront per block, table in LDS; lz4hip_encode_lane.hpp:
+        // one lane per block, tables in a global slab).  Batches large enough to fill the lanes use the
+        // latter.  LZ4HIP_ENCODER=wave|lane overrides (A-B runs).
+        const char* force = getenv("LZ4HIP_ENCODER");
+        bool lane_per_block = d.n_blocks >= 16384;
+        if (force && force[0] == 'w') lane_per_block = false;
+        if (force && force[0] == 'l') lane_per_block = true;
+        if (lane_per_block) {
+            int dev = 0, cus = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            int wpc = kLaneEncodeWavesPerCu;
+            if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
+            int64_t groups = (int64_t)cus * wpc;
+            if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
+            void* ws = nullptr;
+            int rc = workspace(g_fast_ws, (size_t)groups * 64 * kFastTableBytes + 256, &ws);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+            hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                               (unsigned long long*)ws, (uint8_t*)ws + 256);
+        } else {
+            hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d);
+        }
     } else if (mode == LZ4HIP_MODE_HC) {
         int dev = 0, cus = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -134,7 +158,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         int64_t groups = (int64_t)cus * (small ? kHcGroupsPerCu : 1);
         if (groups > d.n_blocks) groups = d.n_blocks;
         void* ws = nullptr;
-        int rc = hc_workspace((size_t)groups * kHcGlobalBytesPerGroup + 256, &ws);
+        int rc = workspace(g_hc_ws, (size_t)groups * kHcGlobalBytesPerGroup + 256, &ws);
         if (rc) return rc;
         // first 8 bytes of the workspace: the work counter of the persistent grid
         HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
@@ -161,7 +185,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
     if (d.n_blocks < 4096 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
     else if (force && (force[0] == 'l' || force[0] == 's' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
-    const bool chunked = force ? force[0] == 'c' : true;
+    const bool chunked = force ? (force[0] == 'c' || force[0] == 'w') : true;   // default lane-per-block decoder
     if (lane_filter >= 0 && chunked) {
         // lane-per-block convergent state machine with a per-lane LDS output ring (lz4hip_decode_chunked.hpp)
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);

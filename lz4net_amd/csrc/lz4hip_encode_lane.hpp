@@ -1,0 +1,161 @@
+// lz4hip_encode_lane.hpp -- batched LZ4 fast block encoder for gfx950, one LANE per block
+// (64 independent blocks per wavefront), bit-exact to the reference.
+//
+// Same functions as lz4hip_encode.hpp: LZ4_compress64kCtx (original/lz4.c:573-771 ==
+// LZ4_compress64kCtx_64, src/LZ4pn/LZ4Codec.Unsafe64.Dirty.cs:303-528) below LZ4_64KLIMIT and
+// LZ4_compressCtx (original/lz4.c:345-562) above it.
+//
+// Why a second mapping: the greedy parse is one chain of dependent hash-table and input reads per
+// block (it has to be, to stay bit-exact), i.e. it is latency bound.  One wavefront per block with the
+// table in LDS keeps at most 10 such chains in flight per CU; one lane per block keeps 64 per
+// wavefront and >1000 per CU.  The price: the 16 KiB table of every resident lane lives in a global
+// scratch slab (random 2-byte accesses), so this mapping is bound by scattered-access throughput
+// instead of latency.  The grid is persistent (work handed out per lane by an atomic counter) so that
+// the slab is sized by residency, not by the batch.
+#pragma once
+#include "lz4hip_common.hpp"
+#include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
+#include "lz4hip_encode.hpp"        // FastTable
+
+namespace lz4hip {
+
+constexpr int kLaneEncodeWavesPerCu = 16;
+
+// exact number of equal bytes in[a + i] == in[b + i] while a + i < limit (b < a)
+LZ4HIP_DEVICE int lane_count_equal(const uint8_t* __restrict__ in, int a, int b, int limit)
+{
+    int n = 0;
+    while (a + n + 8 <= limit) {
+        const uint64_t d = load_u64(in + a + n) ^ load_u64(in + b + n);
+        if (d) return n + (__builtin_ctzll(d) >> 3);
+        n += 8;
+    }
+    while (a + n < limit && in[a + n] == in[b + n]) n++;
+    return n;
+}
+
+// exact copy of n bytes (literal runs)
+LZ4HIP_DEVICE void lane_copy(uint8_t* dst, const uint8_t* __restrict__ src, int n)
+{
+    int k = 0;
+    for (; k + 16 <= n; k += 16) store_v16(dst + k, load_v16(src + k));
+    if (k + 8 <= n) { store_u64(dst + k, load_u64(src + k)); k += 8; }
+    for (; k < n; k++) dst[k] = src[k];
+}
+
+// length bytes after a saturated nibble: floor(rest/255) x 0xFF then rest % 255; returns bytes written
+LZ4HIP_DEVICE int lane_put_length(uint8_t* out, int rest)
+{
+    int k = 0;
+    for (; rest >= 255; rest -= 255) out[k++] = 255;
+    out[k++] = (uint8_t)rest;
+    return k;
+}
+
+template <bool GENERIC>
+LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, uint8_t* out, int cap, uint8_t* table_bytes)
+{
+    typedef FastTable<GENERIC> T;
+    typedef typename T::entry entry;
+    entry* table = (entry*)table_bytes;
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    int ip = 0, anchor = 0, op = 0;
+
+    if (n >= kMinLength) {                                            // lz4.c:615
+        for (int k = 0; k < kFastTableBytes; k += 16) store_v16(table_bytes + k, Vec16{ { 0, 0, 0, 0 } });   // fresh table (lz4.c:583)
+        if (GENERIC) table[T::hash(load_u32(in))] = 0;                // lz4.c:403
+        ip = 1;                                                       // lz4.c:631
+        uint32_t fwd_word = load_u32(in + ip);
+        for (;;) {
+            // ---- find a match: lz4.c:642-654 ----
+            int attempts = 67, probe = ip, ref;
+            uint32_t cur_word;
+            bool out_of_input = false;
+            for (;;) {
+                cur_word = fwd_word;
+                const uint32_t h = T::hash(cur_word);
+                const int step = attempts++ >> 6;
+                ip = probe;
+                probe = ip + step;
+                if (probe > mflimit) { out_of_input = true; break; }
+                fwd_word = load_u32(in + probe);
+                ref = (int)table[h];
+                table[h] = (entry)ip;
+                if (GENERIC && ref < ip - kMaxDistance) continue;     // lz4.c:427
+                if (load_u32(in + ref) == cur_word) break;
+            }
+            if (out_of_input) break;
+
+            // ---- catch up: lz4.c:657 ----
+            while (ip > anchor && ref > 0 && in[ip - 1] == in[ref - 1]) { ip--; ref--; }
+
+            // ---- literals: lz4.c:660-691 ----
+            const int ll = ip - anchor;
+            int token_at = op++;
+            if (op + ll + (ll >> 8) > cap - 8) return 0;             // lz4.c:663
+            if (ll >= 15 && op + (ll - 15) / 255 + 1 + ll > cap) return 0;   // (never write past cap; see lz4hip_encode.hpp)
+            uint32_t token = ll >= 15 ? 0xF0u : (uint32_t)(ll << 4);
+            if (ll >= 15) op += lane_put_length(out + op, ll - 15);
+            lane_copy(out + op, in + anchor, ll);
+            op += ll;
+
+            for (;;) {
+                // ---- offset, match length: lz4.c:693-733 ----
+                const uint32_t off = (uint32_t)(ip - ref) & 0xFFFFu;
+                if (op + 2 > cap) return 0;
+                out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8);
+                op += 2;
+                ip += kMinMatch; ref += kMinMatch; anchor = ip;
+                ip += lane_count_equal(in, ip, ref, matchlimit);
+                const int extra = ip - anchor;
+                if (op + (extra >> 8) > cap - 6) return 0;           // lz4.c:728
+                if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return 0;
+                token |= extra >= 15 ? 15u : (uint32_t)extra;
+                out[token_at] = (uint8_t)token;
+                if (extra >= 15) op += lane_put_length(out + op, extra - 15);
+
+                if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
+                // ---- re-seed the table and test the next position: lz4.c:739-751 ----
+                table[T::hash(load_u32(in + ip - 2))] = (entry)(ip - 2);
+                cur_word = load_u32(in + ip);
+                const uint32_t h = T::hash(cur_word);
+                ref = (int)table[h];
+                table[h] = (entry)ip;
+                const bool in_range = !GENERIC || ref > ip - (kMaxDistance + 1);   // lz4.c:538
+                if (!(in_range && load_u32(in + ref) == cur_word)) break;
+                token_at = op++;                                      // zero-literal sequence (lz4.c:751)
+                token = 0;
+            }
+            anchor = ip++;                                            // lz4.c:754-755
+            fwd_word = load_u32(in + ip);
+        }
+    }
+tail:
+    {   // ---- last literals: lz4.c:758-767 ----
+        const int run = n - anchor;
+        if (op + run + 1 + (run - 15 + 255) / 255 > cap) return 0;   // lz4.c:762
+        out[op++] = (uint8_t)(run >= 15 ? 0xF0 : (run << 4));
+        if (run >= 15) op += lane_put_length(out + op, run - 15);
+        lane_copy(out + op, in + anchor, run);
+        op += run;
+    }
+    return op;
+}
+
+// Persistent grid: every lane pulls block indices from `counter` until the batch is exhausted.
+// `tables` holds one 16 KiB hash table per lane of the grid.
+__global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables)
+{
+    uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kFastTableBytes;
+    for (;;) {
+        const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
+        if (blk >= b.n_blocks) return;
+        const int n = batch_src_len(b, blk), cap = batch_dst_cap(b, blk);
+        const uint8_t* src = batch_src(b, blk);
+        uint8_t* dst = batch_dst(b, blk);
+        b.result[blk] = n < k64kLimit ? lane_encode_fast_block<false>(src, n, dst, cap, table)      // lz4.c:783-785
+                                      : lane_encode_fast_block<true>(src, n, dst, cap, table);
+    }
+}
+
+}  // namespace lz4hip

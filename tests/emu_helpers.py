@@ -57,7 +57,7 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=
     return res, dst
 
 
-def encode(blocks, caps=None, hc=False, groups=2):
+def encode(blocks, caps=None, hc=False, groups=2, lane=False):
     src, sl = pack(blocks)
     if caps is None:
         caps = [len(b) + len(b) // 255 + 16 for b in blocks]
@@ -68,6 +68,8 @@ def encode(blocks, caps=None, hc=False, groups=2):
     args = (_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
     if hc:
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
+    elif lane:
+        lib().emu_encode_fast_lane(*args, 1)
     else:
         lib().emu_encode_fast(*args)
     return res, dst

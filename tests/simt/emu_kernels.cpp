@@ -9,6 +9,7 @@
 #include "lz4hip_decode_staged.hpp"
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
+#include "lz4hip_encode_lane.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
 #include "lz4hip_hc.hpp"
@@ -98,6 +99,18 @@ void emu_encode_hc(const uint8_t* src, int64_t src_stride, const int32_t* src_le
     simt::launch(dim3((unsigned)groups), dim3(64), (size_t)lds, [=] { encode_hc_kernel(b, counter, chains, lds); });
 }
 #endif
+
+void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                          int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)groups * 64 * kFastTableBytes, 0x5A);     // poisoned: the kernel must zero its tables
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* tables = ws.data() + 256;
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables); });
+}
 
 void emu_synth(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n, uint8_t* out, int64_t stride, int len)
 {

@@ -54,7 +54,15 @@ def test_golden_synth_vectors(gpu, oracle):
             assert sha(dst[i, :res[i]]) == e[ksha], (i, hc, e["dist"], e["n"])
 
 
-def test_fast_encode_bit_exact(gpu, oracle):
+@pytest.fixture(params=["wave", "lane"])
+def encoder(request):
+    """Both block->hardware mappings of the fast encoder (lz4hip_encode.hpp / lz4hip_encode_lane.hpp)."""
+    os.environ["LZ4HIP_ENCODER"] = request.param
+    yield request.param
+    del os.environ["LZ4HIP_ENCODER"]
+
+
+def test_fast_encode_bit_exact(gpu, oracle, encoder):
     blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000, 200000), seeds=(5, 6))
     res, dst = gpu.encode(blocks)
     for i, a in enumerate(blocks):
@@ -73,7 +81,7 @@ def test_hc_encode_bit_exact(gpu, oracle):
         assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
 
 
-def test_limited_output(gpu, oracle):
+def test_limited_output(gpu, oracle, encoder):
     # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
     for hc in (False, True):
@@ -139,7 +147,7 @@ def test_decode_error_codes(gpu, oracle, decoder):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-def test_fuzzer_matrix(gpu, oracle, decoder):
+def test_fuzzer_matrix(gpu, oracle, decoder, encoder):
     # original/fuzzer.c:149-227 on 32 KiB fuzzer-generated buffers, batched
     LEN, N = 1 << 15, 96
     blocks = [oracle.gen(2, 99, i, 1, LEN)[0] for i in range(N)]

@@ -97,9 +97,10 @@ def test_decode_error_codes_match_oracle(oracle, lane):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-def test_encode_fast_bit_exact(oracle):
-    blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6))
-    res, dst = emu.encode(blocks)
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_encode_fast_bit_exact(oracle, lane):
+    blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6) if lane else (5,))
+    res, dst = emu.encode(blocks, lane=lane)
     for i, a in enumerate(blocks):
         want = oracle.compress(a)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
@@ -107,13 +108,14 @@ def test_encode_fast_bit_exact(oracle):
         assert (dst[i, compress_bound(a.size):] == 0xA5).all()
 
 
-def test_encode_fast_limited_output(oracle):
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_encode_fast_limited_output(oracle, lane):
     # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
     lens = [len(oracle.compress(a)) for a in blocks]
     for delta in (0, -1, -7):
         caps = [max(l + delta, 0) for l in lens]
-        res, dst = emu.encode(blocks, caps=caps)
+        res, dst = emu.encode(blocks, caps=caps, lane=lane)
         for i, a in enumerate(blocks):
             want = oracle.compress_raw(a, caps[i])[0]
             assert res[i] == want, (i, delta, res[i], want)
