@@ -25,6 +25,14 @@ constexpr int kLaneEncodeWavesPerCu = 16;
 LZ4HIP_DEVICE int lane_count_equal(const uint8_t* __restrict__ in, int a, int b, int limit)
 {
     int n = 0;
+    while (a + n + 16 <= limit) {                      // long runs (e.g. zero pages): 16 bytes per step
+        const Vec16 x = load_v16(in + a + n), y = load_v16(in + b + n);
+        const uint64_t d0 = (x.w[0] ^ y.w[0]) | ((uint64_t)(x.w[1] ^ y.w[1]) << 32);
+        const uint64_t d1 = (x.w[2] ^ y.w[2]) | ((uint64_t)(x.w[3] ^ y.w[3]) << 32);
+        if (d0) return n + (__builtin_ctzll(d0) >> 3);
+        if (d1) return n + 8 + (__builtin_ctzll(d1) >> 3);
+        n += 16;
+    }
     while (a + n + 8 <= limit) {
         const uint64_t d = load_u64(in + a + n) ^ load_u64(in + b + n);
         if (d) return n + (__builtin_ctzll(d) >> 3);
