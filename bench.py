@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--hc-blocks", type=int, default=1 << 14, help="blocks for the LZ4HC extra (0 = skip)")
+    ap.add_argument("--hc-blocks", type=int, default=1 << 16, help="blocks for the LZ4HC extra (0 = skip)")
     ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
     ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
@@ -300,7 +300,7 @@ def main():
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if args.decoder == "wave" or
                        (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
-                       else "lz4hip::decode_chunked_kernel<true,256> (one lane per block, LDS output ring)"),
+                       else "lz4hip::decode_chunked_kernel<true,128> (one lane per block, LDS output ring)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

@@ -12,6 +12,7 @@
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
+#include "lz4hip_hc_lane.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
@@ -154,6 +155,33 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // 16-bit heads (64 KiB of LDS, two workgroups per CU) when every block is known to be <= 64 KiB:
         // uniform length, or per-block lengths with src_len_all carrying an upper bound (0 = unknown).
         const bool small = b->src_len_all > 0 && b->src_len_all <= 65536;
+        // Large batches: one lane per block (lz4hip_hc_lane.hpp), state in a per-lane global slab; if the slab
+        // cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
+        // LZ4HIP_HC=wave|lane overrides (A-B runs).
+        const char* force = getenv("LZ4HIP_HC");
+        bool lane_per_block = d.n_blocks >= 4096;
+        if (force && force[0] == 'w') lane_per_block = false;
+        if (force && force[0] == 'l') lane_per_block = true;
+        if (lane_per_block) {
+            const size_t slab = small ? kHcLaneSlab16 : kHcLaneSlab32;
+            int wpc = kHcLaneWavesPerCu;
+            if (const char* e = getenv("LZ4HIP_HC_WAVES_PER_CU")) wpc = atoi(e);
+            void* ws = nullptr;
+            int64_t groups = 0;
+            for (; wpc >= 1; wpc /= 2) {
+                groups = (int64_t)cus * wpc;
+                if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
+                if (workspace(g_hc_ws, (size_t)groups * 64 * slab + 256, &ws) == 0) break;
+                ws = nullptr;
+            }
+            if (ws) {
+                HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+                hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                   (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
         const int lds_bytes = small ? kHcLdsHeads16 : kHcLdsHeads32;
         int64_t groups = (int64_t)cus * (small ? kHcGroupsPerCu : 1);
         if (groups > d.n_blocks) groups = d.n_blocks;

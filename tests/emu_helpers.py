@@ -66,7 +66,9 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
     dst = np.full((len(blocks), ds), 0xA5, np.uint8)
     res = np.zeros(len(blocks), np.int32)
     args = (_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
-    if hc:
+    if hc and lane:
+        lib().emu_encode_hc_lane(*args, 1, int(max(len(b) for b in blocks) > 65536))
+    elif hc:
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
     elif lane:
         lib().emu_encode_fast_lane(*args, 1)

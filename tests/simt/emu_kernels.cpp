@@ -13,6 +13,7 @@
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
 #include "lz4hip_hc.hpp"
+#include "lz4hip_hc_lane.hpp"
 #endif
 
 using namespace lz4hip;
@@ -111,6 +112,21 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
     uint8_t* tables = ws.data() + 256;
     simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables); });
 }
+
+#ifdef LZ4HIP_HAVE_HC
+void emu_encode_hc_lane(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups, int heads32)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    const size_t slab = heads32 ? kHcLaneSlab32 : kHcLaneSlab16;
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)groups * 64 * slab, 0x5A);      // poisoned
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* slabs = ws.data() + 256;
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_lane_kernel(b, counter, slabs, (unsigned long long)slab); });
+}
+#endif
 
 void emu_synth(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n, uint8_t* out, int64_t stride, int len)
 {

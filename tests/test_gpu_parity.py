@@ -72,7 +72,14 @@ def test_fast_encode_bit_exact(gpu, oracle, encoder):
         assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
 
 
-def test_hc_encode_bit_exact(gpu, oracle):
+@pytest.fixture(params=["wave", "lane"])
+def hc_mapping(request):
+    os.environ["LZ4HIP_HC"] = request.param
+    yield request.param
+    del os.environ["LZ4HIP_HC"]
+
+
+def test_hc_encode_bit_exact(gpu, oracle, hc_mapping):
     blocks = _blocks(oracle, sizes=SIZES + (65537, 70000, 150000), seeds=(5,))
     res, dst = gpu.encode(blocks, hc=True)
     for i, a in enumerate(blocks):
@@ -81,7 +88,7 @@ def test_hc_encode_bit_exact(gpu, oracle):
         assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
 
 
-def test_limited_output(gpu, oracle, encoder):
+def test_limited_output(gpu, oracle, encoder, hc_mapping):
     # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
     for hc in (False, True):

@@ -144,3 +144,33 @@ def test_checksum_and_compare(oracle):
     b[1, 17] ^= 1; b[4, 4999] ^= 0x80; b[4, 4998] ^= 0x80
     assert emu.compare(a, a, [5000] * 5) == 0
     assert emu.compare(a, b, [5000] * 5) == 3
+
+
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_encode_hc_bit_exact(oracle, lane):
+    # LZ4HC: several blocks per persistent workgroup (stale-state check), 16- and 32-bit heads
+    sizes = (0, 1, 12, 13, 14, 64, 300, 4096) if not lane else (0, 1, 12, 13, 14, 64, 300, 4096, 20000, 65536)
+    blocks = _blocks(oracle, sizes=sizes)
+    res, dst = emu.encode(blocks, hc=True, groups=2, lane=lane)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+    big = [oracle.gen(2, 3, 0, 1, 70000)[0]] + ([oracle.gen(3, 3, 0, 1, 65536)[0]] if not lane else [])
+    res, dst = emu.encode(big, hc=True, groups=1, lane=lane)
+    for i, a in enumerate(big):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want) and np.array_equal(dst[i, :res[i]], want), (i, a.size)
+
+
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+def test_encode_hc_limited_output(oracle, lane):
+    blocks = _blocks(oracle, sizes=(13, 300, 4096))
+    lens = [len(oracle.compress(a, hc=True)) for a in blocks]
+    for delta in (0, -1, -7):
+        caps = [max(l + delta, 0) for l in lens]
+        res, dst = emu.encode(blocks, caps=caps, hc=True, lane=lane)
+        for i, a in enumerate(blocks):
+            want = oracle.compress_raw(a, caps[i], hc=True)[0]
+            assert res[i] == want, (i, delta, res[i], want)
+            assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
