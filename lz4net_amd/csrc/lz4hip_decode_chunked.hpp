@@ -9,9 +9,11 @@
 // arithmetic but (1) vector-memory instructions -- a wavefront instruction whose 64 lanes touch 64
 // different lines costs 3..30 CU-cycles PER LANE in the texture-address/L1 pipeline, (2) divergence --
 // a sequence-per-iteration loop executes the union of all lanes' paths (~1300 instructions and ~40
-// vector-memory instructions per iteration in lz4hip_decode_staged.hpp), and (3) any load that is
+// vector-memory instructions per iteration in lz4hip_decode_staged.hpp), (3) any load that is
 // consumed in the iteration that issues it stalls the whole wavefront for a memory round trip, and
-// with 64 lanes "some lane needs one" is true every iteration.  So:
+// with 64 lanes "some lane needs one" is true every iteration, and (4) exec-mask bookkeeping: the
+// first version of this kernel spent ~600 of its ~1400 instructions on s_and_saveexec / s_or / s_andn2
+// for nested ifs and bool state.  So:
 //   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free); sequences are
 //     appended exactly; matches whose offset fits the ring are served from LDS; finished output leaves
 //     in 16-byte pieces that L2 merges into full lines;
@@ -20,8 +22,9 @@
 //     its loads are requested at least one header before they are needed;
 //   * far matches and long literal runs stream through a 16-byte register pair that is requested at
 //     the END of an iteration and consumed in the next ones;
-//   * anything else (length runs of 0xFF bytes, the last bytes of the input, offset 0) takes a slow
-//     byte-wise path that is correct but rare.
+//   * the hot paths are straight-line code on integer state (selects, unconditional LDS accesses whose
+//     result is discarded when not needed); only rare events are branches: length runs of 0xFF bytes,
+//     the last bytes of the input, offset 0, errors, the final literal run.
 #pragma once
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
@@ -30,8 +33,10 @@ namespace lz4hip {
 
 constexpr int kChunkedRingBytes = 128;     // per-lane output ring (LDS = 64 x this per wavefront)
 
-// what the next chunk of a lane's current copy is made from
+// what the next chunk of a lane's current copy is made from (>= kSlowLit: rare byte-wise sources)
 enum ChunkMode { kIdle = 0, kReg = 1, kNear = 2, kGlobal = 3, kSlowLit = 4, kZeroOff = 5 };
+// what has to be parsed / started once the current copy is finished
+enum ChunkPending { kNeedToken = 0, kNeedMatch = 1, kNeedHeader = 2 };
 
 template <bool KNOWN, int OUT_BYTES>
 LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8_t* __restrict__ src, int iend,
@@ -43,13 +48,12 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     uint64_t* out_q = (uint64_t*)lds + lane;                         // qword k of this lane at out_q[(k & (OUT_Q-1)) * 64]
 #define OUTQ(k) out_q[((k) & (OUT_Q - 1)) * 64]
 
-    // ---- per-lane state ----
+    // ---- per-lane state (plain integers: bools would live in SGPR lane masks and cost s_and/s_or traffic) ----
     int ip = 0;                  // position of the next header to parse
     int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 16)
     uint64_t tail = 0;           // qword containing op: low (op & 7) bytes valid, rest 0
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
-    int win_pos = 0;
-    bool win_ok = false;
+    int win_pos = 0, win_ok = 0;
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
     int stride = 8;              // bytes per chunk (8, or a multiple of the offset for a periodic match)
     uint64_t cv = 0, cv2 = 0;    // kReg: this chunk / next chunk (literals from the window, or the period)
@@ -57,12 +61,10 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     int gcount = 0;              // kGlobal: valid 8-byte halves in (g0, g1)
     const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
     int lit_src = 0;             // kSlowLit: position of the next literal byte in src
-    int off = 0, ml = 0;         // pending / current match
-    bool match_pending = false;  // a match (off, ml) follows the current literal run
-    bool hdr_pending = false;    // offset + match length are still to be parsed at `ip` after the literals
+    int off = 8, ml = 0;         // pending / current match
+    int pend = kNeedToken;
     uint32_t token = 0;
-    bool final_run = false;
-    int result = 0;
+    int final_run = 0, result = 0;
 
     // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
     // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes.
@@ -75,169 +77,168 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             const Vec16 n_ = load_v16(src + win_pos + 16);                                              \
             w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
         } else if ((pos) + 32 <= iend) {                                                                \
-            win_pos = (pos); win_ok = true;                                                             \
+            win_pos = (pos); win_ok = 1;                                                                \
             const Vec16 m_ = load_v16(src + win_pos), n_ = load_v16(src + win_pos + 16);                \
             w0 = m_.w[0] | ((uint64_t)m_.w[1] << 32); w1 = m_.w[2] | ((uint64_t)m_.w[3] << 32);        \
             w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
-        } else win_ok = false;                                                                          \
+        } else win_ok = 0;                                                                              \
     } while (0)
 
     SLIDE_WINDOW(0);
 
     for (;;) {
         // =========================== (b) one chunk of the current copy ===========================
-        if (rem > 0 && !(mode == kGlobal && gcount == 0)) {
-            const int n = rem < stride ? rem : stride;
-            uint64_t v;
-            if (mode == kReg) { v = cv; cv = cv2; }
-            else if (mode == kNear) {
-                const int sp = op - off, k = sp >> 3, s = (sp & 7) * 8;
-                const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
-                v = s ? (q0 >> s) | (q1 << (64 - s)) : q0;
-            } else if (mode == kGlobal) { v = g0; g0 = g1; gcount--; }
-            else if (mode == kSlowLit) {
-                v = 0; for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b);
-                lit_src += n;
-            } else {                                                 // kZeroOff: out[i] = out[i], keep what dst holds
-                v = 0; for (int b = 0; b < n; b++) v |= (uint64_t)dst[op + b] << (8 * b);
+        {
+            const bool can = rem > 0 && !(mode == kGlobal && gcount == 0);
+            const int n = can ? (rem < stride ? rem : stride) : 0;
+            // ring source (read unconditionally; only used by kNear)
+            const int sp = op - off, ks = sp >> 3, ss = (sp & 7) * 8;
+            const uint64_t q0 = OUTQ(ks), q1 = OUTQ(ks + 1);
+            const uint64_t vnear = ss ? (q0 >> ss) | (q1 << (64 - ss)) : q0;
+            uint64_t v = mode == kReg ? cv : (mode == kGlobal ? g0 : vnear);
+            if (mode >= kSlowLit && can) {                           // rare byte-wise sources
+                v = 0;
+                if (mode == kSlowLit) { for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b); lit_src += n; }
+                else                  { for (int b = 0; b < n; b++) v |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
             }
-            if (n < 8) v &= (1ull << (8 * n)) - 1ull;
+            const bool used_reg = can && mode == kReg, used_g = can && mode == kGlobal;
+            cv = used_reg ? cv2 : cv;
+            g0 = used_g ? g1 : g0;
+            gcount -= used_g ? 1 : 0;
+            // append the low n bytes of v (n == 0: rewrites the current qword with itself)
+            v = n >= 8 ? v : (v & ((1ull << (8 * n)) - 1ull));
             const int k = op >> 3, s = (op & 7) * 8;
             const uint64_t cur = tail | (v << s);
+            const uint64_t spill = s ? (v >> (64 - s)) : 0ull;       // bytes that belong to the next qword
             OUTQ(k) = cur;
-            if (s + 8 * n >= 64) {
-                tail = s ? (v >> (64 - s)) : 0ull;
-                if (s + 8 * n > 64) OUTQ(k + 1) = tail;
-            } else tail = cur;
+            OUTQ(k + 1) = spill;                                     // (a not-yet-produced position when nothing spills)
+            tail = (s + 8 * n >= 64) ? spill : cur;
             op += n; rem -= n;
-            if (rem == 0) mode = kIdle;
+            mode = rem == 0 ? (int)kIdle : mode;
         }
 
         // =========================== (a) header parsing ===========================
-        if (rem == 0) {
-            if (!hdr_pending && !match_pending && !final_run) {
-                // ---- token [+ literal length] at ip ----
-                uint64_t lo = 0, hi = 0;
-                if (win_ok) {
-                    const int d = ip - win_pos;
-                    const bool up = d >= 8;
-                    const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1, x2 = up ? w3 : w2;
-                    const int s = 8 * (d & 7);
-                    lo = s ? (x0 >> s) | (x1 << (64 - s)) : x0;
-                    hi = s ? (x1 >> s) | (x2 << (64 - s)) : x1;
+        int err = 0;                                                 // nonzero: this lane's stream is corrupt, value = return code
+        if (rem == 0 && pend == kNeedToken && !final_run) {
+            // ---- token [+ one literal-length byte] at ip, from the window ----
+            const int d = ip - win_pos;
+            const bool up = d >= 8;
+            const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1, x2 = up ? w3 : w2;
+            const int sw = 8 * (d & 7);
+            const uint64_t lo = sw ? (x0 >> sw) | (x1 << (64 - sw)) : x0;
+            const uint64_t hi = sw ? (x1 >> sw) | (x2 << (64 - sw)) : x1;
+            token = (uint32_t)lo & 255u;
+            const uint32_t mlc = token & 15u;
+            const uint32_t b1 = (uint32_t)(lo >> 8) & 255u;
+            const bool ext1 = (token >> 4) == 15u;
+            int ll = (int)(token >> 4) + (ext1 ? (int)b1 : 0);
+            int pos = ip + 1 + (ext1 ? 1 : 0);                       // position after token (+ literal-length bytes)
+            if (!win_ok || (ext1 && b1 == 255u)) {                   // rare: byte-wise, lz4.c:844 / :957-961
+                token = ip < iend ? src[ip] : 0u;
+                ll = (int)(token >> 4);
+                pos = ip + 1;
+                if (ll == 15) {
+                    uint32_t b = 255;
+                    if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
+                    else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
                 }
-                token = win_ok ? (uint32_t)lo & 255u : (ip < iend ? src[ip] : 0u);
-                int ll = (int)(token >> 4);
-                const uint32_t mlc = token & 15u;
-                int pos = ip + 1;                                    // position after token (+ literal-length bytes)
-                if (ll == 15) {                                      // lz4.c:844 / :957-961
-                    const uint32_t b1 = (uint32_t)(lo >> 8) & 255u;
-                    if (win_ok && b1 != 255u) { ll += (int)b1; pos++; }           // one length byte, from the window
-                    else {
-                        uint32_t b = 255;
-                        if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
-                        else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
+            }
+            const bool in_win = win_ok && ll <= 11;                  // literals, offset and first match-length byte are in (lo, hi)
+            const int lit_end = op + ll;
+            const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
+            const int lit_mode = in_win ? (int)kReg : (pos + ll + 16 <= iend ? (int)kGlobal : (int)kSlowLit);
+            cv = in_win ? ((lo >> 8) | (hi << 56)) : cv;
+            cv2 = in_win ? (hi >> 8) : cv2;
+            gptr = lit_mode == kGlobal ? src + pos : gptr;
+            gcount = lit_mode == kGlobal ? 0 : gcount;
+            lit_src = pos;
+            rem = ll; stride = 8;
+            mode = ll ? lit_mode : (int)kIdle;
+            if (last) {                                              // rare: final literal run, lz4.c:851-858 / :965-975
+                if (KNOWN) { if (lit_end != oend || pos + ll > iend) err = -pos; }
+                else       { if (lit_end > oend || pos + ll != iend) err = -pos; }
+                final_run = 1;
+                result = KNOWN ? pos + ll : lit_end;
+            } else {
+                if (KNOWN && pos + ll > iend) err = -pos;            // never read literals past the source
+                // offset + match length from the same 16 bytes when they are all there
+                const int e = 3 + ll;                                // index of the first match-length byte (<= 14 when in_win)
+                const uint32_t extb = (uint32_t)((e < 8 ? lo >> (8 * (e & 7)) : hi >> (8 * (e & 7))) & 255u);
+                // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
+                const bool fast = in_win && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
+                const int sh = 8 * ((1 + ll) & 15);                  // 8 .. 96 when in_win
+                const uint64_t vo = sh < 64 ? ((lo >> sh) | (hi << ((64 - sh) & 63))) : (hi >> (sh & 63));
+                const int p_off = ip + 3 + ll;                       // after the offset
+                const int ml_fast = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
+                const int ip_fast = p_off + (mlc == 15u ? 1 : 0);
+                if (fast) {
+                    off = (int)(vo & 0xFFFFu);
+                    ml = ml_fast;
+                    if (err == 0 && lit_end - off < 0) err = -p_off;               // lz4.c:863 / :980
+                    if (err == 0 && lit_end + ml > oend - kLastLiterals) err = -ip_fast;   // lz4.c:893 / :1024
+                }
+                pend = fast ? (int)kNeedMatch : (int)kNeedHeader;
+                ip = fast ? ip_fast : pos + ll;
+                SLIDE_WINDOW(ip);                                    // a needed load travels while this sequence is copied
+            }
+        }
+        if (rem == 0 && pend == kNeedHeader && err == 0) {
+            // ---- offset + match length at ip (after a literal run that did not fit the token's window) ----
+            int p = ip + 2;
+            bool have = false;
+            if (win_ok) {
+                const int d = ip - win_pos;
+                const bool up = d >= 8;
+                const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1;
+                const int sw = 8 * (d & 7);
+                const uint64_t lo = sw ? (x0 >> sw) | (x1 << (64 - sw)) : x0;
+                off = (int)((uint32_t)lo & 0xFFFFu);
+                ml = (int)(token & 15u);
+                const uint32_t b = (uint32_t)(lo >> 16) & 255u;
+                if (ml != 15) have = true;
+                else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
+            }
+            if (!have) {                                             // rare: byte-wise, lz4.c:862-866 / :979-997
+                p = ip;
+                off = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
+                p += 2;
+                ml = (int)(token & 15u);
+                if (ml == 15) {
+                    if (KNOWN) {
+                        uint32_t b;
+                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
+                        ml += (int)b; p++;
+                    } else {
+                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
                     }
                 }
-                const bool in_win = win_ok && ll <= 11;              // literals, offset and first match-length byte are in (lo, hi)
-                const int lit_end = op + ll;
-                const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
-                if (last) {                                          // lz4.c:851-858 / :965-975
-                    if (KNOWN) { if (lit_end != oend) return -pos; if (pos + ll > iend) return -pos; }
-                    else       { if (lit_end > oend) return -pos; if (pos + ll != iend) return -pos; }
-                    final_run = true;
-                    result = KNOWN ? pos + ll : lit_end;
-                } else {
-                    if (KNOWN && pos + ll > iend) return -pos;       // never read literals past the source
-                }
-                // ---- where the literals come from ----
-                rem = ll; stride = 8;
-                if (in_win) { mode = kReg; cv = (lo >> 8) | (hi << 56); cv2 = hi >> 8; }
-                else if (pos + ll + 16 <= iend) { mode = kGlobal; gptr = src + pos; gcount = 0; }
-                else { mode = kSlowLit; lit_src = pos; }
-                if (!last) {
-                    bool fast = false;
-                    if (in_win) {
-                        // offset + match length from the same 16 bytes
-                        const int e = 3 + ll;                        // index of the first match-length byte (<= 14)
-                        const uint32_t extb = (uint32_t)((e < 8 ? lo >> (8 * e) : hi >> (8 * (e - 8))) & 255u);
-                        // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
-                        fast = mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1)));
-                        if (fast) {
-                            const int sh = 8 * (1 + ll);             // 8 .. 96
-                            const uint64_t v = sh < 64 ? ((lo >> sh) | (hi << (64 - sh))) : (hi >> (sh - 64));
-                            off = (int)(v & 0xFFFFu);
-                            const int p = ip + 3 + ll;               // after the offset
-                            if (lit_end - off < 0) return -p;        // lz4.c:863 / :980
-                            ml = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
-                            ip = p + (mlc == 15u ? 1 : 0);
-                            if (lit_end + ml > oend - kLastLiterals) return -ip;    // lz4.c:893 / :1024
-                            match_pending = true;
-                        }
-                    }
-                    if (!fast) { hdr_pending = true; ip = pos + ll; }   // offset/length are parsed after the literals
-                    SLIDE_WINDOW(ip);                                // a needed load travels while this sequence is copied
-                }
-                if (rem == 0) mode = kIdle;
             }
-            if (rem == 0 && hdr_pending) {
-                // ---- offset + match length at ip (after a literal run that did not fit the token's window) ----
-                int p = ip + 2;
-                bool have = false;
-                if (win_ok) {
-                    const int d = ip - win_pos;
-                    const bool up = d >= 8;
-                    const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1;
-                    const int s = 8 * (d & 7);
-                    const uint64_t lo = s ? (x0 >> s) | (x1 << (64 - s)) : x0;
-                    off = (int)((uint32_t)lo & 0xFFFFu);
-                    ml = (int)(token & 15u);
-                    const uint32_t b = (uint32_t)(lo >> 16) & 255u;
-                    if (ml != 15) have = true;
-                    else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
-                }
-                if (!have) {                                         // slow: byte-wise, lz4.c:862-866 / :979-997
-                    p = ip;
-                    off = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
-                    p += 2;
-                    ml = (int)(token & 15u);
-                    if (ml == 15) {
-                        if (KNOWN) {
-                            uint32_t b;
-                            while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
-                            ml += (int)b; p++;
-                        } else {
-                            while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
-                        }
-                    }
-                }
-                if (op - off < 0) return -(ip + 2);
-                ml += kMinMatch;
-                if (op + ml > oend - kLastLiterals) return -p;
-                ip = p;
-                hdr_pending = false; match_pending = true;
-                SLIDE_WINDOW(ip);
-            }
-            if (rem == 0 && match_pending) {
-                // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
-                match_pending = false;
-                rem = ml; stride = 8;
-                if (off == 0) mode = kZeroOff;
-                else if (off < 8) {
-                    // periodic: build the period once; every chunk appends a multiple of `off` bytes
-                    const int sp = op - off, k = sp >> 3, s = (sp & 7) * 8;
-                    const uint64_t q0 = OUTQ(k), q1 = OUTQ(k + 1);
-                    uint64_t pat = (s ? (q0 >> s) | (q1 << (64 - s)) : q0) & ((1ull << (8 * off)) - 1ull);
-                    int sh = 8 * off;
-                    pat |= pat << sh; sh += sh;
-                    if (sh < 64) { pat |= pat << sh; sh += sh; }
-                    if (sh < 64) { pat |= pat << sh; }
-                    cv = pat; cv2 = pat;
-                    stride = (int)((0x76586880u >> (4 * off)) & 15u);   // off 1..7 -> 8,8,6,8,5,6,7
-                    mode = kReg;
-                } else if (off <= kNearMax) mode = kNear;
-                else { mode = kGlobal; gptr = dst + (op - off); gcount = 0; }   // older than the ring: already flushed
-            }
+            ml += kMinMatch;
+            if (op - off < 0) err = -(ip + 2);
+            else if (op + ml > oend - kLastLiterals) err = -p;
+            ip = p;
+            pend = kNeedMatch;
+            SLIDE_WINDOW(ip);
+        }
+        if (err != 0) return err;
+        if (rem == 0 && pend == kNeedMatch) {
+            // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
+            // the period of an offset < 8 match is built for every lane (straight-line) and kept if needed
+            const int osafe = (off >= 1 && off < 8) ? off : 1;
+            const int sp = op - osafe, ks = sp >> 3, ss = (sp & 7) * 8;
+            const uint64_t q0 = OUTQ(ks), q1 = OUTQ(ks + 1);
+            uint64_t pat = (ss ? (q0 >> ss) | (q1 << (64 - ss)) : q0) & ((1ull << (8 * osafe)) - 1ull);
+            pat |= pat << (8 * osafe);                               // period x2 (<= 56-bit shift)
+            pat |= osafe < 4 ? pat << (16 * osafe) : 0ull;           // x4 while it still fits
+            pat |= osafe < 2 ? pat << 32 : 0ull;                     // x8 for offset 1
+            const bool periodic = off >= 1 && off < 8;
+            cv = periodic ? pat : cv; cv2 = periodic ? pat : cv2;
+            stride = periodic ? (int)((0x76586880u >> (4 * osafe)) & 15u) : 8;   // off 1..7 -> 8,8,6,8,5,6,7
+            mode = off == 0 ? (int)kZeroOff : (periodic ? (int)kReg : (off <= kNearMax ? (int)kNear : (int)kGlobal));
+            gptr = mode == kGlobal ? dst + (op - off) : gptr;        // older than the ring: already flushed
+            gcount = mode == kGlobal ? 0 : gcount;
+            rem = ml;
+            pend = kNeedToken;
         }
 
         // =========================== (d) request the next 16 source bytes ===========================
