@@ -50,7 +50,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
 
     // ---- per-lane state (plain integers: bools would live in SGPR lane masks and cost s_and/s_or traffic) ----
     int ip = 0;                  // position of the next header to parse
-    int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 16)
+    int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 64)
     uint64_t tail = 0;           // qword containing op: low (op & 7) bytes valid, rest 0
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
     int win_pos = 0, win_ok = 0;
@@ -243,23 +243,28 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
 
         // =========================== (d) request the next 16 source bytes ===========================
         // (consumed from the next iteration on; a far source lies > OUT_BYTES - 16 behind op, the fetch
-        //  reads at most 16 bytes past the chunk start, and everything up to op - 23 has been flushed)
+        //  reads at most 16 bytes past the chunk start, and everything up to op - 71 has been flushed)
         if (mode == kGlobal && gcount == 0 && rem > 0) {
             const Vec16 w = load_v16(gptr);
             g0 = w.w[0] | ((uint64_t)w.w[1] << 32); g1 = w.w[2] | ((uint64_t)w.w[3] << 32);
             gcount = 2; gptr += 16;
         }
 
-        // =========================== (c) flush one finished 16-byte piece ===========================
-        if (op - flushed >= 16) {
-            const uint64_t a = OUTQ(flushed >> 3), b2 = OUTQ((flushed >> 3) + 1);
-            const Vec16 v16 = { { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32) } };
-            store_v16(dst + flushed, v16);
-            flushed += 16;
+        // =========================== (c) flush finished output, 64 bytes at a time ===========================
+        // (four back-to-back 16-byte stores fill whole 32/64-byte sectors: PMC showed 16-byte pieces issued
+        //  iterations apart being written back to HBM as partial sectors, 2x the output bytes)
+        if (op - flushed >= 64) {
+            const int kq = flushed >> 3;
+            for (int j = 0; j < 4; j++) {
+                const uint64_t a = OUTQ(kq + 2 * j), b2 = OUTQ(kq + 2 * j + 1);
+                const Vec16 v16 = { { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32) } };
+                store_v16(dst + flushed + 16 * j, v16);
+            }
+            flushed += 64;
         }
 
         if (final_run && rem == 0) {
-            // ---- end of block: write out the last (< 32) bytes exactly ----
+            // ---- end of block: write out the last (< 72) bytes exactly ----
             while (op - flushed >= 8) { store_u64(dst + flushed, OUTQ(flushed >> 3)); flushed += 8; }
             if (flushed < op) {
                 const uint64_t q = OUTQ(flushed >> 3);
