@@ -284,7 +284,7 @@ def main():
     # taken from the committed rocprofv3 --pmc summary of this exact workload (tools/pmc_decoder.sh: separate
     # FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes, per launch); null when the configuration differs.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_decode_chunked_kernel_D2_2p20blocks_2launches.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_decode_chunked_kernel_D2_2p20blocks_2launches.json")
     if world == 1 and args.dist == 2 and n == (1 << 20) and args.decoder == "auto" and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         traffic = int((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / pmc["launches_summed"])
@@ -311,7 +311,7 @@ def main():
                        else "lz4hip::decode_chunked_kernel<true,128> (one lane per block, LDS output ring)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01/pmc_decode_chunked_kernel_D2_2p20blocks_2launches.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)" if traffic else None,
+            "traffic_source": "profiles/r01/pmc_traffic_decode_chunked_kernel_D2_2p20blocks_2launches.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch)" if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),
         },
         "cpu_baseline": cpu,
