@@ -143,10 +143,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the codec")
-    torch.cuda.set_device(local_rank)
+    # (LZ4HIP_BENCH_SHARE_GPU=1: every rank uses cuda:0 -- only for exercising the N>1 code path on a 1-GPU box)
+    torch.cuda.set_device(0 if os.environ.get("LZ4HIP_BENCH_SHARE_GPU") else local_rank)
     if world > 1:
+        # The data path has no collective (blocks are independent, sharded round-robin); ranks only meet at
+        # the timing barriers and to combine three scalars, which gloo does over host memory.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -157,9 +160,9 @@ def main():
     _lib.lib()
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
 
     # ---- size the batch to the memory actually free on this GPU ------------------------------------
     n = args.blocks
@@ -186,8 +189,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ok = wl.verify()
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    stats = torch.tensor([float(wl.algorithmic_bytes), float(wl.comp_bytes), float(ok)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64)
+    stats = torch.tensor([float(wl.algorithmic_bytes), float(wl.comp_bytes), float(ok)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
