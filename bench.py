@@ -17,6 +17,7 @@ workload on this box's host cores.  `extras` carries the other distributions and
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -45,6 +46,19 @@ def parse_args():
     ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    sys.stdout.flush()
+    fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(fd, 1)
+        os.close(fd)
 
 
 def event_ms(fn, torch):
@@ -149,7 +163,9 @@ def main():
         # The data path has no collective (blocks are independent, sharded round-robin); ranks only meet at
         # the timing barriers and to combine three scalars, which gloo does over host memory.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        with _stdout_to_stderr():      # gloo announces its connections on stdout; stdout is reserved for the JSON line
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
 
     import __graft_entry__ as entry
     if rank == 0:
