@@ -73,7 +73,13 @@ LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, 
         for (int k = 0; k < kFastTableBytes; k += 16) store_v16(table_bytes + k, Vec16{ { 0, 0, 0, 0 } });   // fresh table (lz4.c:583)
         if (GENERIC) table[T::hash(load_u32(in))] = 0;                // lz4.c:403
         ip = 1;                                                       // lz4.c:631
-        uint32_t fwd_word = load_u32(in + ip);
+        // 8-byte register window over the input for the (mostly sequential) forward reads of the search loop
+        uint64_t fw = load_u64(in + ip);                              // n >= 13: in-bounds
+        int fw_pos = ip;
+#define FWD_WORD(pos) ((uint32_t)(fw >> (8 * ((pos) - fw_pos))))
+#define FWD_REFILL(pos)                                                                         \
+        do { if ((pos) - fw_pos > 4 || (pos) < fw_pos) { fw_pos = (pos) + 8 <= n ? (pos) : n - 8; fw = load_u64(in + fw_pos); } } while (0)
+        uint32_t fwd_word = FWD_WORD(ip);
         for (;;) {
             // ---- find a match: lz4.c:642-654 ----
             int attempts = 67, probe = ip, ref;
@@ -86,7 +92,8 @@ LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, 
                 ip = probe;
                 probe = ip + step;
                 if (probe > mflimit) { out_of_input = true; break; }
-                fwd_word = load_u32(in + probe);
+                FWD_REFILL(probe);
+                fwd_word = FWD_WORD(probe);
                 ref = (int)table[h];
                 table[h] = (entry)ip;
                 if (GENERIC && ref < ip - kMaxDistance) continue;     // lz4.c:427
@@ -98,45 +105,71 @@ LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, 
             while (ip > anchor && ref > 0 && in[ip - 1] == in[ref - 1]) { ip--; ref--; }
 
             // ---- literals: lz4.c:660-691 ----
-            const int ll = ip - anchor;
+            int ll = ip - anchor;
             int token_at = op++;
             if (op + ll + (ll >> 8) > cap - 8) return 0;             // lz4.c:663
             if (ll >= 15 && op + (ll - 15) / 255 + 1 + ll > cap) return 0;   // (never write past cap; see lz4hip_encode.hpp)
             uint32_t token = ll >= 15 ? 0xF0u : (uint32_t)(ll << 4);
-            if (ll >= 15) op += lane_put_length(out + op, ll - 15);
-            lane_copy(out + op, in + anchor, ll);
+            // Short literal runs (the common case) are not copied now: token, literals and offset leave as ONE
+            // 16-byte store once the match length -- the low nibble of the token -- is known.  The bytes of that
+            // store beyond the offset are overwritten by whatever is emitted next.
+            bool packed = ll <= 13 && token_at + 16 <= cap && anchor + 16 <= n;
+            if (!packed) {
+                if (ll >= 15) op += lane_put_length(out + op, ll - 15);
+                lane_copy(out + op, in + anchor, ll);
+            }
             op += ll;
 
             for (;;) {
                 // ---- offset, match length: lz4.c:693-733 ----
                 const uint32_t off = (uint32_t)(ip - ref) & 0xFFFFu;
                 if (op + 2 > cap) return 0;
-                out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8);
+                if (!packed) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
                 op += 2;
+                const int lit_from = anchor;
                 ip += kMinMatch; ref += kMinMatch; anchor = ip;
                 ip += lane_count_equal(in, ip, ref, matchlimit);
                 const int extra = ip - anchor;
                 if (op + (extra >> 8) > cap - 6) return 0;           // lz4.c:728
                 if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return 0;
                 token |= extra >= 15 ? 15u : (uint32_t)extra;
-                out[token_at] = (uint8_t)token;
+                if (packed) {
+                    uint64_t l0 = 0, l1 = 0;
+                    if (ll > 0) { const Vec16 w = load_v16(in + lit_from); l0 = w.w[0] | ((uint64_t)w.w[1] << 32); l1 = w.w[2] | ((uint64_t)w.w[3] << 32); }
+                    // keep ll literal bytes, shift them up by one byte, token below, offset above
+                    if (ll < 8) { l0 &= (1ull << (8 * ll)) - 1ull; l1 = 0; }
+                    else if (ll < 16) l1 &= (1ull << (8 * (ll - 8))) - 1ull;
+                    uint64_t v0 = (l0 << 8) | token, v1 = (l1 << 8) | (l0 >> 56);
+                    const int sh = 8 * (1 + ll);                     // 8 .. 112
+                    if (sh < 64) { v0 |= (uint64_t)off << sh; v1 |= sh > 48 ? (uint64_t)off >> (64 - sh) : 0ull; }
+                    else v1 |= (uint64_t)off << (sh - 64);
+                    const Vec16 o = { { (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32) } };
+                    store_v16(out + token_at, o);
+                } else {
+                    out[token_at] = (uint8_t)token;
+                }
                 if (extra >= 15) op += lane_put_length(out + op, extra - 15);
 
                 if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
                 // ---- re-seed the table and test the next position: lz4.c:739-751 ----
-                table[T::hash(load_u32(in + ip - 2))] = (entry)(ip - 2);
-                cur_word = load_u32(in + ip);
+                fw_pos = ip - 2; fw = load_u64(in + fw_pos);           // ip <= mflimit: ip - 2 + 8 <= n
+                table[T::hash(FWD_WORD(ip - 2))] = (entry)(ip - 2);
+                cur_word = FWD_WORD(ip);
                 const uint32_t h = T::hash(cur_word);
                 ref = (int)table[h];
                 table[h] = (entry)ip;
                 const bool in_range = !GENERIC || ref > ip - (kMaxDistance + 1);   // lz4.c:538
                 if (!(in_range && load_u32(in + ref) == cur_word)) break;
                 token_at = op++;                                      // zero-literal sequence (lz4.c:751)
-                token = 0;
+                token = 0; ll = 0;
+                packed = token_at + 16 <= cap;
             }
             anchor = ip++;                                            // lz4.c:754-755
-            fwd_word = load_u32(in + ip);
+            FWD_REFILL(ip);
+            fwd_word = FWD_WORD(ip);
         }
+#undef FWD_WORD
+#undef FWD_REFILL
     }
 tail:
     {   // ---- last literals: lz4.c:758-767 ----
