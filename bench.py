@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--hc-blocks", type=int, default=1 << 16, help="blocks for the LZ4HC extra (0 = skip)")
     ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
-    ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
+    ap.add_argument("--encoder", choices=["auto", "lane", "wave", "sm"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
 

@@ -11,6 +11,7 @@
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
+#include "lz4hip_encode_sm.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_synth.hpp"
@@ -128,25 +129,35 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // one lane per block, tables in a global slab).  Batches large enough to fill the lanes use the
         // latter.  LZ4HIP_ENCODER=wave|lane overrides (A-B runs).
         const char* force = getenv("LZ4HIP_ENCODER");
-        bool lane_per_block = d.n_blocks >= 16384;
-        if (force && force[0] == 'w') lane_per_block = false;
-        if (force && force[0] == 'l') lane_per_block = true;
-        if (lane_per_block) {
+        // 's' (default for large batches): lane-per-block state machine; 'l': lane-per-block direct; 'w': wavefront
+        char pick = d.n_blocks >= 16384 ? 's' : 'w';
+        if (force && (force[0] == 'w' || force[0] == 'l' || force[0] == 's')) pick = force[0];
+        if (pick != 'w') {
             int dev = 0, cus = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            int wpc = kLaneEncodeWavesPerCu;
+            int wpc = pick == 's' ? kSmEncodeWavesPerCu : kLaneEncodeWavesPerCu;
             if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
             int64_t groups = (int64_t)cus * wpc;
             if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
+            const size_t per_lane = pick == 's' ? (size_t)kSmTableBytes : (size_t)kFastTableBytes;
             void* ws = nullptr;
-            int rc = workspace(g_fast_ws, (size_t)groups * 64 * kFastTableBytes + 256, &ws);
+            int rc = workspace(g_fast_ws, (size_t)groups * 64 * per_lane + 256, &ws);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-            hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                               (unsigned long long*)ws, (uint8_t*)ws + 256);
+            if (pick == 's') {
+                // epoch-tagged tables: cleared once per launch instead of once per block
+                HIP_TRY(hipMemsetAsync(ws, 0, (size_t)groups * 64 * per_lane + 256, stream));
+                hipLaunchKernelGGL(encode_fast_sm_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                   (unsigned long long*)ws, (uint8_t*)ws + 256);
+                // blocks of LZ4_64KLIMIT bytes and more use the u32-table variant: wavefront kernel, filtered
+                hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 1);
+            } else {
+                HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+                hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                   (unsigned long long*)ws, (uint8_t*)ws + 256);
+            }
         } else {
-            hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d);
+            hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 0);
         }
     } else if (mode == LZ4HIP_MODE_HC) {
         int dev = 0, cus = 0;

@@ -193,12 +193,15 @@ tail:
 
 // One wavefront (= one workgroup of 64 threads) per block; 16 KiB of dynamic LDS per workgroup,
 // so up to 10 blocks are resident per CU.
-__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b)
+// only_generic != 0: handle just the blocks of LZ4_64KLIMIT bytes and more (the rest of the batch is encoded
+// by the lane-per-block state machine, lz4hip_encode_sm.hpp).
+__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int only_generic)
 {
     LZ4HIP_DYN_LDS(lds);
     const int64_t blk = (int64_t)blockIdx.x;
     if (blk >= b.n_blocks) return;
     const int n = wv::uniform(batch_src_len(b, blk));
+    if (only_generic && n < k64kLimit) return;
     const int cap = wv::uniform(batch_dst_cap(b, blk));
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);

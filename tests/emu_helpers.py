@@ -70,6 +70,8 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
         lib().emu_encode_hc_lane(*args, 1, int(max(len(b) for b in blocks) > 65536))
     elif hc:
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
+    elif lane == "sm":
+        lib().emu_encode_fast_sm(*args, 1)
     elif lane:
         lib().emu_encode_fast_lane(*args, 1)
     else:

@@ -10,6 +10,7 @@
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
+#include "lz4hip_encode_sm.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
 #include "lz4hip_hc.hpp"
@@ -82,7 +83,7 @@ void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_
                      int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
-    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b); });
+    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, 0); });
 }
 
 #ifdef LZ4HIP_HAVE_HC
@@ -111,6 +112,18 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* tables = ws.data() + 256;
     simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables); });
+}
+
+void emu_encode_fast_sm(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)groups * 64 * kSmTableBytes, 0);          // the launch zeroes the slab
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* tables = ws.data() + 256;
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_sm_kernel(b, counter, tables); });
+    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, 1); });
 }
 
 #ifdef LZ4HIP_HAVE_HC

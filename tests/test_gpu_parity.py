@@ -54,7 +54,7 @@ def test_golden_synth_vectors(gpu, oracle):
             assert sha(dst[i, :res[i]]) == e[ksha], (i, hc, e["dist"], e["n"])
 
 
-@pytest.fixture(params=["wave", "lane"])
+@pytest.fixture(params=["wave", "lane", "sm"])
 def encoder(request):
     """Both block->hardware mappings of the fast encoder (lz4hip_encode.hpp / lz4hip_encode_lane.hpp)."""
     os.environ["LZ4HIP_ENCODER"] = request.param

@@ -97,7 +97,7 @@ def test_decode_error_codes_match_oracle(oracle, lane):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "sm"], ids=["wave-per-block", "lane-per-block", "lane-state-machine"])
 def test_encode_fast_bit_exact(oracle, lane):
     blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6) if lane else (5,))
     res, dst = emu.encode(blocks, lane=lane)
@@ -108,7 +108,7 @@ def test_encode_fast_bit_exact(oracle, lane):
         assert (dst[i, compress_bound(a.size):] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "sm"], ids=["wave-per-block", "lane-per-block", "lane-state-machine"])
 def test_encode_fast_limited_output(oracle, lane):
     # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
