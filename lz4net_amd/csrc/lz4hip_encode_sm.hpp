@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(64) encode_fast_sm_kernel(Batch b, unsigned lo
     Vec16 r_a = { { 0, 0, 0, 0 } }, r_b = { { 0, 0, 0, 0 } };   // COUNT: 16 bytes at ip side / ref side; LIT: literal chunk in r_a
     uint64_t r_pm = 0;                               // POST_W: 8 bytes at ip-2
     Vec16 r_l = { { 0, 0, 0, 0 } };                  // the literal bytes of a packed sequence
+    Vec16 r_c = { { 0, 0, 0, 0 } }, r_d = { { 0, 0, 0, 0 } };   // LIT / TAIL: literal chunk
 
 #define SM_FWD_WORD(pos) ((uint32_t)(fw >> (8 * ((pos) - fw_pos))))
 #define SM_FWD_REFILL(pos) do { if ((pos) - fw_pos > 4 || (pos) < fw_pos) { fw_pos = (pos); fw = load_u64(in + fw_pos); } } while (0)
@@ -85,7 +86,19 @@ __global__ void __launch_bounds__(64) encode_fast_sm_kernel(Batch b, unsigned lo
         if (ip + 4 + 16 <= matchlimit) { r_a = load_v16(in + ip + 4); r_b = load_v16(in + ref + 4); } \
     } while (0)
 
-    for (;;) {
+    // Two-phase clock: a response register is only ever READ in one phase and WRITTEN (requested) in the
+    // other -- or read before it is re-requested inside one branch -- so no branch of an iteration has to
+    // wait for a load issued earlier in the same iteration by another branch (the compiler cannot know that
+    // the lanes of two branches are disjoint).  The natural order of the parse alternates anyway:
+    //   even: PROBE_T / POST_T (read r_tv, request r_ref8/r_ip8), COUNT (read r_a/r_b/r_l, request r_a/r_b or r_pm)
+    //   odd : PROBE_R / POST_R (read r_ref8/r_ip8, request r_tv or r_a/r_b/r_l), POST_W (read r_pm, request r_tv), next block,
+    //         byte-wise catch-up;   either: LIT / TAIL (own registers)
+    // A lane whose state belongs to the other phase idles for one iteration (rare: long matches, long literals).
+    for (unsigned iter = 1;; iter++) {
+        const bool even = (iter & 1u) == 0u;
+        const bool even_state = state == kSmProbeT || state == kSmPostT || state == kSmCount;
+        const bool any_phase = state == kSmLit || state == kSmTail;        // own response registers (r_c / r_d)
+        if (!any_phase && even != even_state) continue;
         if (state == kSmNextBlock) {
             blk = (int64_t)atomicAdd(counter, 1ull);
             if (blk >= b.n_blocks) return;
@@ -203,11 +216,11 @@ __global__ void __launch_bounds__(64) encode_fast_sm_kernel(Batch b, unsigned lo
             // ---- a literal run that does not fit the packed store: 16 bytes per round trip ----
             if (lit_k >= 0) {                                          // chunk requested last time has arrived
                 const int m = ll - lit_k < 16 ? ll - lit_k : 16;
-                if (m == 16) store_v16(out + op + lit_k, r_a);
+                if (m == 16) store_v16(out + op + lit_k, r_c);
                 else for (int i = 0; i < m; i++) out[op + lit_k + i] = in[lit_from + lit_k + i];
                 lit_k += m;
             } else lit_k = 0;
-            if (lit_k < ll) { if (ll - lit_k >= 16) r_a = load_v16(in + lit_from + lit_k); }
+            if (lit_k < ll) { if (ll - lit_k >= 16) r_c = load_v16(in + lit_from + lit_k); }
             else { op += ll; SM_START_COUNT(); }
         } else {                                                       // kSmTail: last literals (lz4.c:758-767)
             const int run = n - anchor;
@@ -216,13 +229,13 @@ __global__ void __launch_bounds__(64) encode_fast_sm_kernel(Batch b, unsigned lo
                 out[op++] = (uint8_t)(run >= 15 ? 0xF0 : (run << 4));
                 if (run >= 15) op += lane_put_length(out + op, run - 15);
                 lit_k = 0;
-                if (run >= 16) r_a = load_v16(in + anchor);
+                if (run >= 16) r_d = load_v16(in + anchor);
             } else {
                 const int m = run - lit_k < 16 ? run - lit_k : 16;
-                if (m == 16) store_v16(out + op + lit_k, r_a);
+                if (m == 16) store_v16(out + op + lit_k, r_d);
                 else for (int i = 0; i < m; i++) out[op + lit_k + i] = in[anchor + lit_k + i];
                 lit_k += m;
-                if (run - lit_k >= 16) r_a = load_v16(in + anchor + lit_k);
+                if (run - lit_k >= 16) r_d = load_v16(in + anchor + lit_k);
             }
             if (lit_k >= run) SM_FINISH(op + run);
         }
