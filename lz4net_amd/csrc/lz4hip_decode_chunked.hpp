@@ -1,7 +1,8 @@
 // lz4hip_decode_chunked.hpp -- lane-per-block LZ4 decoder as a CONVERGENT state machine:
-// every loop iteration every lane (b) produces at most 8 output bytes from whatever source its state
-// says, (a) parses a sequence header if its copy is finished, (d) requests the next 16 source bytes if
-// it is copying from global memory, (c) flushes one 16-byte piece of finished output.
+// every loop iteration every lane (b) produces at most 16 output bytes from whatever source its state
+// says, (a) parses a sequence header if its copy is finished -- appending the sequence's literals right
+// away when they sit in the header window --, (c) flushes 64 bytes of finished output, (d) requests the
+// next 16 source bytes if it is copying from global memory.
 // Same functions / return conventions as lz4hip_decode.hpp (LZ4_uncompress, original/lz4.c:812-914;
 // LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
 //
@@ -44,6 +45,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
 {
     if (!KNOWN && iend == 0) return 0;                               // lz4.c:946 returns -(0)
     constexpr int OUT_Q = OUT_BYTES / 8;
+    static_assert(OUT_BYTES >= 128, "ring too small for 16-byte appends + 64-byte flushes");
     constexpr int kNearMax = OUT_BYTES - 16;                         // largest offset served from the ring
     uint64_t* out_q = (uint64_t*)lds + lane;                         // qword k of this lane at out_q[(k & (OUT_Q-1)) * 64]
 #define OUTQ(k) out_q[((k) & (OUT_Q - 1)) * 64]
@@ -55,8 +57,8 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
     int win_pos = 0, win_ok = 0;
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
-    int stride = 8;              // bytes per chunk (8, or a multiple of the offset for a periodic match)
-    uint64_t cv = 0, cv2 = 0;    // kReg: this chunk / next chunk (literals from the window, or the period)
+    int stride = 16;             // bytes per chunk (16, a multiple of a short period, or the offset when source and chunk would overlap)
+    uint64_t cv = 0, cv2 = 0;    // kReg: 16 bytes of the periodic stream of an offset < 8 match
     uint64_t g0 = 0, g1 = 0;     // kGlobal: fetched source bytes
     int gcount = 0;              // kGlobal: valid 8-byte halves in (g0, g1)
     const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
@@ -65,6 +67,25 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     int pend = kNeedToken;
     uint32_t token = 0;
     int final_run = 0, result = 0;
+
+    // Append the low n (0..16) bytes of (vlo, vhi) to the output ring.  Up to three qwords are written; a qword
+    // that receives nothing is redirected onto the current one, so no byte behind `op - 120` is ever touched.
+#define APPEND(vlo_, vhi_, n_)                                                                          \
+    do {                                                                                                \
+        const int an_ = (n_);                                                                           \
+        uint64_t al_ = (vlo_), ah_ = (vhi_);                                                            \
+        al_ = an_ >= 8 ? al_ : (al_ & ((1ull << ((8 * an_) & 63)) - 1ull));                                    \
+        ah_ = an_ >= 16 ? ah_ : (an_ > 8 ? (ah_ & ((1ull << (8 * (an_ & 7))) - 1ull)) : 0ull);          \
+        const int ak_ = op >> 3, as_ = (op & 7) * 8, at_ = as_ + 8 * an_;                               \
+        const uint64_t q0_ = tail | (al_ << as_);                                                       \
+        const uint64_t q1_ = as_ ? (al_ >> ((64 - as_) & 63)) | (ah_ << as_) : ah_;                             \
+        const uint64_t q2_ = as_ ? (ah_ >> ((64 - as_) & 63)) : 0ull;                                           \
+        OUTQ(ak_) = q0_;                                                                                \
+        OUTQ(at_ > 64 ? ak_ + 1 : ak_) = at_ > 64 ? q1_ : q0_;                                          \
+        OUTQ(at_ > 128 ? ak_ + 2 : ak_) = at_ > 128 ? q2_ : q0_;                                        \
+        tail = at_ < 64 ? q0_ : (at_ < 128 ? (at_ == 64 ? 0ull : q1_) : (at_ == 128 ? 0ull : q2_));    \
+        op += an_;                                                                                      \
+    } while (0)
 
     // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
     // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes.
@@ -87,33 +108,26 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     SLIDE_WINDOW(0);
 
     for (;;) {
-        // =========================== (b) one chunk of the current copy ===========================
+        // =========================== (b) one chunk (<= 16 bytes) of the current copy ===========================
         {
             const bool can = rem > 0 && !(mode == kGlobal && gcount == 0);
-            const int n = can ? (rem < stride ? rem : stride) : 0;
+            int n = can ? (rem < stride ? rem : stride) : 0;
             // ring source (read unconditionally; only used by kNear)
             const int sp = op - off, ks = sp >> 3, ss = (sp & 7) * 8;
-            const uint64_t q0 = OUTQ(ks), q1 = OUTQ(ks + 1);
-            const uint64_t vnear = ss ? (q0 >> ss) | (q1 << (64 - ss)) : q0;
-            uint64_t v = mode == kReg ? cv : (mode == kGlobal ? g0 : vnear);
-            if (mode >= kSlowLit && can) {                           // rare byte-wise sources
-                v = 0;
-                if (mode == kSlowLit) { for (int b = 0; b < n; b++) if (lit_src + b < iend) v |= (uint64_t)src[lit_src + b] << (8 * b); lit_src += n; }
-                else                  { for (int b = 0; b < n; b++) v |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
+            const uint64_t r0 = OUTQ(ks), r1 = OUTQ(ks + 1), r2 = OUTQ(ks + 2);
+            const uint64_t near_lo = ss ? (r0 >> ss) | (r1 << (64 - ss)) : r0;
+            const uint64_t near_hi = ss ? (r1 >> ss) | (r2 << (64 - ss)) : r1;
+            uint64_t vlo = mode == kReg ? cv : (mode == kGlobal ? g0 : near_lo);
+            uint64_t vhi = mode == kReg ? cv2 : (mode == kGlobal ? g1 : near_hi);
+            if (mode >= kSlowLit && can) {                           // rare byte-wise sources, 8 bytes at a time
+                n = n < 8 ? n : 8;
+                vlo = 0; vhi = 0;
+                if (mode == kSlowLit) { for (int b = 0; b < n; b++) if (lit_src + b < iend) vlo |= (uint64_t)src[lit_src + b] << (8 * b); lit_src += n; }
+                else                  { for (int b = 0; b < n; b++) vlo |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
             }
-            const bool used_reg = can && mode == kReg, used_g = can && mode == kGlobal;
-            cv = used_reg ? cv2 : cv;
-            g0 = used_g ? g1 : g0;
-            gcount -= used_g ? 1 : 0;
-            // append the low n bytes of v (n == 0: rewrites the current qword with itself)
-            v = n >= 8 ? v : (v & ((1ull << (8 * n)) - 1ull));
-            const int k = op >> 3, s = (op & 7) * 8;
-            const uint64_t cur = tail | (v << s);
-            const uint64_t spill = s ? (v >> (64 - s)) : 0ull;       // bytes that belong to the next qword
-            OUTQ(k) = cur;
-            OUTQ(k + 1) = spill;                                     // (a not-yet-produced position when nothing spills)
-            tail = (s + 8 * n >= 64) ? spill : cur;
-            op += n; rem -= n;
+            gcount = (can && mode == kGlobal) ? 0 : gcount;
+            APPEND(vlo, vhi, n);
+            rem -= n;
             mode = rem == 0 ? (int)kIdle : mode;
         }
 
@@ -147,13 +161,14 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             const int lit_end = op + ll;
             const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
             const int lit_mode = in_win ? (int)kReg : (pos + ll + 16 <= iend ? (int)kGlobal : (int)kSlowLit);
-            cv = in_win ? ((lo >> 8) | (hi << 56)) : cv;
-            cv2 = in_win ? (hi >> 8) : cv2;
             gptr = lit_mode == kGlobal ? src + pos : gptr;
             gcount = lit_mode == kGlobal ? 0 : gcount;
             lit_src = pos;
-            rem = ll; stride = 8;
-            mode = ll ? lit_mode : (int)kIdle;
+            stride = 16;
+            // literals that sit in the window are appended right now; longer runs are streamed by stage (b)
+            APPEND((lo >> 8) | (hi << 56), hi >> 8, in_win ? ll : 0);
+            rem = in_win ? 0 : ll;
+            mode = rem ? lit_mode : (int)kIdle;
             if (last) {                                              // rare: final literal run, lz4.c:851-858 / :965-975
                 if (KNOWN) { if (lit_end != oend || pos + ll > iend) err = -pos; }
                 else       { if (lit_end > oend || pos + ll != iend) err = -pos; }
@@ -223,7 +238,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         if (err != 0) return err;
         if (rem == 0 && pend == kNeedMatch) {
             // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
-            // the period of an offset < 8 match is built for every lane (straight-line) and kept if needed
+            // the 16-byte period of an offset < 8 match is built for every lane (straight-line) and kept if needed
             const int osafe = (off >= 1 && off < 8) ? off : 1;
             const int sp = op - osafe, ks = sp >> 3, ss = (sp & 7) * 8;
             const uint64_t q0 = OUTQ(ks), q1 = OUTQ(ks + 1);
@@ -231,23 +246,20 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             pat |= pat << (8 * osafe);                               // period x2 (<= 56-bit shift)
             pat |= osafe < 4 ? pat << (16 * osafe) : 0ull;           // x4 while it still fits
             pat |= osafe < 2 ? pat << 32 : 0ull;                     // x8 for offset 1
+            // bytes 8..15 of the periodic stream: it also has period L8 = off * (8 / off) <= 8
+            const int l8 = (int)((0x76586880u >> (4 * osafe)) & 15u);    // off 1..7 -> 8,8,6,8,5,6,7
+            uint64_t pat_hi = l8 == 8 ? pat : (pat >> (8 * (8 - l8)));
+            pat_hi |= l8 == 8 ? 0ull : (pat_hi << (8 * l8));
             const bool periodic = off >= 1 && off < 8;
-            cv = periodic ? pat : cv; cv2 = periodic ? pat : cv2;
-            stride = periodic ? (int)((0x76586880u >> (4 * osafe)) & 15u) : 8;   // off 1..7 -> 8,8,6,8,5,6,7
+            cv = periodic ? pat : cv; cv2 = periodic ? pat_hi : cv2;
+            const int l16 = 16 - (int)((0x24101000u >> (4 * osafe)) & 15u);   // off 1..7 -> 16,16,15,16,15,12,14
+            // chunk size: a multiple of the period, or at most `off` when the source would overlap the chunk
+            stride = periodic ? l16 : ((off >= 16 || off == 0) ? 16 : off);
             mode = off == 0 ? (int)kZeroOff : (periodic ? (int)kReg : (off <= kNearMax ? (int)kNear : (int)kGlobal));
             gptr = mode == kGlobal ? dst + (op - off) : gptr;        // older than the ring: already flushed
             gcount = mode == kGlobal ? 0 : gcount;
             rem = ml;
             pend = kNeedToken;
-        }
-
-        // =========================== (d) request the next 16 source bytes ===========================
-        // (consumed from the next iteration on; a far source lies > OUT_BYTES - 16 behind op, the fetch
-        //  reads at most 16 bytes past the chunk start, and everything up to op - 71 has been flushed)
-        if (mode == kGlobal && gcount == 0 && rem > 0) {
-            const Vec16 w = load_v16(gptr);
-            g0 = w.w[0] | ((uint64_t)w.w[1] << 32); g1 = w.w[2] | ((uint64_t)w.w[3] << 32);
-            gcount = 2; gptr += 16;
         }
 
         // =========================== (c) flush finished output, 64 bytes at a time ===========================
@@ -263,8 +275,17 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             flushed += 64;
         }
 
+        // =========================== (d) request the next 16 source bytes ===========================
+        // (consumed in the next iteration; a far source lies > OUT_BYTES - 16 behind op, the fetch reads 16 bytes
+        //  from op - off, and at most 63 + 27 bytes behind op are still unflushed)
+        if (mode == kGlobal && gcount == 0 && rem > 0) {
+            const Vec16 w = load_v16(gptr);
+            g0 = w.w[0] | ((uint64_t)w.w[1] << 32); g1 = w.w[2] | ((uint64_t)w.w[3] << 32);
+            gcount = 2; gptr += 16;
+        }
+
         if (final_run && rem == 0) {
-            // ---- end of block: write out the last (< 72) bytes exactly ----
+            // ---- end of block: write out the last (< 96) bytes exactly ----
             while (op - flushed >= 8) { store_u64(dst + flushed, OUTQ(flushed >> 3)); flushed += 8; }
             if (flushed < op) {
                 const uint64_t q = OUTQ(flushed >> 3);
@@ -274,6 +295,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         }
     }
 #undef OUTQ
+#undef APPEND
 #undef SLIDE_WINDOW
 }
 
