@@ -15,9 +15,10 @@
 // with 64 lanes "some lane needs one" is true every iteration, and (4) exec-mask bookkeeping: the
 // first version of this kernel spent ~600 of its ~1400 instructions on s_and_saveexec / s_or / s_andn2
 // for nested ifs and bool state.  So:
-//   * per-lane output ring in LDS (qword-interleaved across lanes: conflict free); sequences are
-//     appended exactly; matches whose offset fits the ring are served from LDS; finished output leaves
-//     in 16-byte pieces that L2 merges into full lines;
+//   * per-lane output ring in LDS (dword-interleaved across lanes: conflict free); appends and ring reads
+//     are byte-granular through v_perm_b32 on aligned dwords (no 64-bit shifts, no masking: bytes written
+//     past the end of an append are overwritten by the next one); matches whose offset fits the ring are
+//     served from LDS; finished output leaves 64 bytes at a time as four back-to-back 16-byte stores;
 //   * every header byte (token, one literal-length byte, <= 11 literals, offset, one match-length byte)
 //     comes out of a 32-byte register window over the compressed stream that slides 16 bytes at a time;
 //     its loads are requested at least one header before they are needed;
@@ -32,35 +33,53 @@
 
 namespace lz4hip {
 
-constexpr int kChunkedRingBytes = 128;     // per-lane output ring (LDS = 64 x this per wavefront)
+constexpr int kChunkedRingBytes = 128;     // per-lane output ring
+constexpr int kChunkedTableBytes = 128;    // byte-permute selectors of the periods 1..7, behind the 64 rings
+constexpr unsigned chunked_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + (unsigned)kChunkedTableBytes; }
 
 // what the next chunk of a lane's current copy is made from (>= kSlowLit: rare byte-wise sources)
 enum ChunkMode { kIdle = 0, kReg = 1, kNear = 2, kGlobal = 3, kSlowLit = 4, kZeroOff = 5 };
 // what has to be parsed / started once the current copy is finished
 enum ChunkPending { kNeedToken = 0, kNeedMatch = 1, kNeedHeader = 2 };
 
+// Entry p (1..7) of the period table: 16 selector bytes, byte b = b mod p (source byte of stream byte b).
+// Written by lanes 0..31 of the wavefront (one dword each) before any lane decodes.
+LZ4HIP_DEVICE void chunked_init_period_table(unsigned char* lds, int lane, int ring_bytes)
+{
+    if (lane < 32) {
+        const uint32_t p = (uint32_t)lane >> 2, j = (uint32_t)lane & 3u;
+        uint32_t v = 0;
+        if (p) for (uint32_t b = 0; b < 4; b++) v |= ((4u * j + b) % p) << (8u * b);
+        ((uint32_t*)(lds + 64 * ring_bytes))[lane] = v;
+    }
+    wv::mem_sync();
+}
+
 template <bool KNOWN, int OUT_BYTES>
 LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8_t* __restrict__ src, int iend,
                                        uint8_t* dst, int oend)
 {
     if (!KNOWN && iend == 0) return 0;                               // lz4.c:946 returns -(0)
-    constexpr int OUT_Q = OUT_BYTES / 8;
-    static_assert(OUT_BYTES >= 128, "ring too small for 16-byte appends + 64-byte flushes");
-    constexpr int kNearMax = OUT_BYTES - 16;                         // largest offset served from the ring
-    uint64_t* out_q = (uint64_t*)lds + lane;                         // qword k of this lane at out_q[(k & (OUT_Q-1)) * 64]
-#define OUTQ(k) out_q[((k) & (OUT_Q - 1)) * 64]
+    constexpr int RW = OUT_BYTES / 4;                                // ring dwords per lane
+    static_assert(OUT_BYTES >= 128 && (OUT_BYTES & (OUT_BYTES - 1)) == 0, "ring: power of two, >= 128 bytes");
+    // An append writes whole dwords, up to 19 bytes past its last byte; those land on ring bytes op-OUT_BYTES+19
+    // and older.  Everything younger must stay intact: ring sources (<= kNearMax back) and unflushed output (< 91 back).
+    constexpr int kNearMax = OUT_BYTES - 20;                         // largest offset served from the ring
+    uint32_t* ring = (uint32_t*)lds + lane;                          // dword k of this lane at ring[(k & (RW-1)) * 64]
+    const uint32_t* period_tab = (const uint32_t*)(lds + 64 * OUT_BYTES);
+#define RING(k) ring[((k) & (RW - 1)) * 64]
 
     // ---- per-lane state (plain integers: bools would live in SGPR lane masks and cost s_and/s_or traffic) ----
     int ip = 0;                  // position of the next header to parse
     int op = 0, flushed = 0;     // bytes produced / bytes already stored to dst (multiple of 64)
-    uint64_t tail = 0;           // qword containing op: low (op & 7) bytes valid, rest 0
-    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // 32-byte window over src[win_pos .. win_pos+32) (valid iff win_ok)
+    uint32_t tail = 0;           // ring dword containing op: its low (op & 3) bytes are output, the rest is junk
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0;   // window src[win_pos .. win_pos+32) (valid iff win_ok)
     int win_pos = 0, win_ok = 0;
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
     int stride = 16;             // bytes per chunk (16, a multiple of a short period, or the offset when source and chunk would overlap)
-    uint64_t cv = 0, cv2 = 0;    // kReg: 16 bytes of the periodic stream of an offset < 8 match
-    uint64_t g0 = 0, g1 = 0;     // kGlobal: fetched source bytes
-    int gcount = 0;              // kGlobal: valid 8-byte halves in (g0, g1)
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // kReg: 16 bytes of the periodic stream of an offset < 8 match
+    uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;   // kGlobal: fetched source bytes
+    int gcount = 0;              // kGlobal: (g0..g3) hold the next chunk
     const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
     int lit_src = 0;             // kSlowLit: position of the next literal byte in src
     int off = 8, ml = 0;         // pending / current match
@@ -68,24 +87,38 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     uint32_t token = 0;
     int final_run = 0, result = 0;
 
-    // Append the low n (0..16) bytes of (vlo, vhi) to the output ring.  Up to three qwords are written; a qword
-    // that receives nothing is redirected onto the current one, so no byte behind `op - 120` is ever touched.
-#define APPEND(vlo_, vhi_, n_)                                                                          \
+    // Append the low n_ bytes of the data dwords to the output ring at op.  The data is rotated to the byte
+    // phase of op with one v_perm_b32 per dword and stored as whole dwords; only the first dword is merged
+    // (with the bytes below op).  Bytes past n_ are junk that the next append overwrites.
+#define APPEND_HEAD()                                                                                   \
+        const uint32_t sb_ = (uint32_t)op & 3u;                                                         \
+        const uint32_t s_ = 0x07060504u - sb_ * 0x01010101u;     /* byte b <- source byte 4 + b - sb */ \
+        const uint32_t keep_ = (1u << (8u * sb_)) - 1u;                                                 \
+        const int k_ = op >> 2
+#define APPEND_TAIL(n_)                                                                                 \
+        op += (n_);                                                                                     \
+        tail = RING(op >> 2)
+#define APPEND4(d0_, d1_, d2_, d3_, n_)                                                                 \
     do {                                                                                                \
-        const int an_ = (n_);                                                                           \
-        uint64_t al_ = (vlo_), ah_ = (vhi_);                                                            \
-        al_ = an_ >= 8 ? al_ : (al_ & ((1ull << ((8 * an_) & 63)) - 1ull));                                    \
-        ah_ = an_ >= 16 ? ah_ : (an_ > 8 ? (ah_ & ((1ull << (8 * (an_ & 7))) - 1ull)) : 0ull);          \
-        const int ak_ = op >> 3, as_ = (op & 7) * 8, at_ = as_ + 8 * an_;                               \
-        const uint64_t q0_ = tail | (al_ << as_);                                                       \
-        const uint64_t q1_ = as_ ? (al_ >> ((64 - as_) & 63)) | (ah_ << as_) : ah_;                             \
-        const uint64_t q2_ = as_ ? (ah_ >> ((64 - as_) & 63)) : 0ull;                                           \
-        OUTQ(ak_) = q0_;                                                                                \
-        OUTQ(at_ > 64 ? ak_ + 1 : ak_) = at_ > 64 ? q1_ : q0_;                                          \
-        OUTQ(at_ > 128 ? ak_ + 2 : ak_) = at_ > 128 ? q2_ : q0_;                                        \
-        tail = at_ < 64 ? q0_ : (at_ < 128 ? (at_ == 64 ? 0ull : q1_) : (at_ == 128 ? 0ull : q2_));    \
-        op += an_;                                                                                      \
+        APPEND_HEAD();                                                                                  \
+        RING(k_) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
+        RING(k_ + 1) = wv::perm(d1_, d0_, s_);                                                          \
+        RING(k_ + 2) = wv::perm(d2_, d1_, s_);                                                          \
+        RING(k_ + 3) = wv::perm(d3_, d2_, s_);                                                          \
+        RING(k_ + 4) = wv::perm(0u, d3_, s_);                                                           \
+        APPEND_TAIL(n_);                                                                                \
     } while (0)
+#define APPEND3(d0_, d1_, d2_, n_)                                                                      \
+    do {                                                                                                \
+        APPEND_HEAD();                                                                                  \
+        RING(k_) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
+        RING(k_ + 1) = wv::perm(d1_, d0_, s_);                                                          \
+        RING(k_ + 2) = wv::perm(d2_, d1_, s_);                                                          \
+        RING(k_ + 3) = wv::perm(0u, d2_, s_);                                                           \
+        APPEND_TAIL(n_);                                                                                \
+    } while (0)
+    // selector that extracts 4 bytes at byte phase (p & 3) from a dword pair: wv::perm(hi, lo, PHASE_SEL(p))
+#define PHASE_SEL(p_) (0x03020100u + ((uint32_t)(p_) & 3u) * 0x01010101u)
 
     // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
     // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes.
@@ -94,14 +127,14 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         const int d_ = (pos) - win_pos;                                                                 \
         if (win_ok && d_ >= 0 && d_ < 16) {                                                             \
         } else if (win_ok && d_ >= 16 && d_ < 32 && win_pos + 48 <= iend) {                             \
-            w0 = w2; w1 = w3; win_pos += 16;                                                            \
+            w0 = w4; w1 = w5; w2 = w6; w3 = w7; win_pos += 16;                                          \
             const Vec16 n_ = load_v16(src + win_pos + 16);                                              \
-            w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
+            w4 = n_.w[0]; w5 = n_.w[1]; w6 = n_.w[2]; w7 = n_.w[3];                                     \
         } else if ((pos) + 32 <= iend) {                                                                \
             win_pos = (pos); win_ok = 1;                                                                \
             const Vec16 m_ = load_v16(src + win_pos), n_ = load_v16(src + win_pos + 16);                \
-            w0 = m_.w[0] | ((uint64_t)m_.w[1] << 32); w1 = m_.w[2] | ((uint64_t)m_.w[3] << 32);        \
-            w2 = n_.w[0] | ((uint64_t)n_.w[1] << 32); w3 = n_.w[2] | ((uint64_t)n_.w[3] << 32);        \
+            w0 = m_.w[0]; w1 = m_.w[1]; w2 = m_.w[2]; w3 = m_.w[3];                                     \
+            w4 = n_.w[0]; w5 = n_.w[1]; w6 = n_.w[2]; w7 = n_.w[3];                                     \
         } else win_ok = 0;                                                                              \
     } while (0)
 
@@ -113,20 +146,23 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             const bool can = rem > 0 && !(mode == kGlobal && gcount == 0);
             int n = can ? (rem < stride ? rem : stride) : 0;
             // ring source (read unconditionally; only used by kNear)
-            const int sp = op - off, ks = sp >> 3, ss = (sp & 7) * 8;
-            const uint64_t r0 = OUTQ(ks), r1 = OUTQ(ks + 1), r2 = OUTQ(ks + 2);
-            const uint64_t near_lo = ss ? (r0 >> ss) | (r1 << (64 - ss)) : r0;
-            const uint64_t near_hi = ss ? (r1 >> ss) | (r2 << (64 - ss)) : r1;
-            uint64_t vlo = mode == kReg ? cv : (mode == kGlobal ? g0 : near_lo);
-            uint64_t vhi = mode == kReg ? cv2 : (mode == kGlobal ? g1 : near_hi);
+            const int sp = op - off, ks = sp >> 2;
+            const uint32_t sr = PHASE_SEL(sp);
+            const uint32_t r0 = RING(ks), r1 = RING(ks + 1), r2 = RING(ks + 2), r3 = RING(ks + 3), r4 = RING(ks + 4);
+            uint32_t v0 = wv::perm(r1, r0, sr), v1 = wv::perm(r2, r1, sr), v2 = wv::perm(r3, r2, sr), v3 = wv::perm(r4, r3, sr);
+            v0 = mode == kReg ? c0 : (mode == kGlobal ? g0 : v0);
+            v1 = mode == kReg ? c1 : (mode == kGlobal ? g1 : v1);
+            v2 = mode == kReg ? c2 : (mode == kGlobal ? g2 : v2);
+            v3 = mode == kReg ? c3 : (mode == kGlobal ? g3 : v3);
             if (mode >= kSlowLit && can) {                           // rare byte-wise sources, 8 bytes at a time
                 n = n < 8 ? n : 8;
-                vlo = 0; vhi = 0;
-                if (mode == kSlowLit) { for (int b = 0; b < n; b++) if (lit_src + b < iend) vlo |= (uint64_t)src[lit_src + b] << (8 * b); lit_src += n; }
-                else                  { for (int b = 0; b < n; b++) vlo |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
+                uint64_t acc = 0;
+                if (mode == kSlowLit) { for (int b = 0; b < n; b++) if (lit_src + b < iend) acc |= (uint64_t)src[lit_src + b] << (8 * b); lit_src += n; }
+                else                  { for (int b = 0; b < n; b++) acc |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
+                v0 = (uint32_t)acc; v1 = (uint32_t)(acc >> 32);
             }
             gcount = (can && mode == kGlobal) ? 0 : gcount;
-            APPEND(vlo, vhi, n);
+            APPEND4(v0, v1, v2, v3, n);
             rem -= n;
             mode = rem == 0 ? (int)kIdle : mode;
         }
@@ -134,16 +170,16 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         // =========================== (a) header parsing ===========================
         int err = 0;                                                 // nonzero: this lane's stream is corrupt, value = return code
         if (rem == 0 && pend == kNeedToken && !final_run) {
-            // ---- token [+ one literal-length byte] at ip, from the window ----
+            // ---- the 16 bytes at ip, from the window: dword shift network + one byte permute per dword ----
             const int d = ip - win_pos;
-            const bool up = d >= 8;
-            const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1, x2 = up ? w3 : w2;
-            const int sw = 8 * (d & 7);
-            const uint64_t lo = sw ? (x0 >> sw) | (x1 << (64 - sw)) : x0;
-            const uint64_t hi = sw ? (x1 >> sw) | (x2 << (64 - sw)) : x1;
-            token = (uint32_t)lo & 255u;
+            const bool q2 = (d & 8) != 0, q1 = (d & 4) != 0;
+            const uint32_t y0 = q2 ? w2 : w0, y1 = q2 ? w3 : w1, y2 = q2 ? w4 : w2, y3 = q2 ? w5 : w3, y4 = q2 ? w6 : w4, y5 = q2 ? w7 : w5;
+            const uint32_t z0 = q1 ? y1 : y0, z1 = q1 ? y2 : y1, z2 = q1 ? y3 : y2, z3 = q1 ? y4 : y3, z4 = q1 ? y5 : y4;
+            const uint32_t sx = PHASE_SEL(d);
+            const uint32_t x0 = wv::perm(z1, z0, sx), x1 = wv::perm(z2, z1, sx), x2 = wv::perm(z3, z2, sx), x3 = wv::perm(z4, z3, sx);
+            token = x0 & 255u;
             const uint32_t mlc = token & 15u;
-            const uint32_t b1 = (uint32_t)(lo >> 8) & 255u;
+            const uint32_t b1 = (x0 >> 8) & 255u;
             const bool ext1 = (token >> 4) == 15u;
             int ll = (int)(token >> 4) + (ext1 ? (int)b1 : 0);
             int pos = ip + 1 + (ext1 ? 1 : 0);                       // position after token (+ literal-length bytes)
@@ -157,7 +193,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                     else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
                 }
             }
-            const bool in_win = win_ok && ll <= 11;                  // literals, offset and first match-length byte are in (lo, hi)
+            const bool in_win = win_ok && ll <= 11;                  // literals, offset and first match-length byte are in x0..x3
             const int lit_end = op + ll;
             const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
             const int lit_mode = in_win ? (int)kReg : (pos + ll + 16 <= iend ? (int)kGlobal : (int)kSlowLit);
@@ -165,8 +201,8 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             gcount = lit_mode == kGlobal ? 0 : gcount;
             lit_src = pos;
             stride = 16;
-            // literals that sit in the window are appended right now; longer runs are streamed by stage (b)
-            APPEND((lo >> 8) | (hi << 56), hi >> 8, in_win ? ll : 0);
+            // literals that sit in the window (bytes 1..11 of x) are appended right now; longer runs are streamed by stage (b)
+            APPEND3(wv::alignbyte(x1, x0, 1), wv::alignbyte(x2, x1, 1), wv::alignbyte(x3, x2, 1), in_win ? ll : 0);
             rem = in_win ? 0 : ll;
             mode = rem ? lit_mode : (int)kIdle;
             if (last) {                                              // rare: final literal run, lz4.c:851-858 / :965-975
@@ -178,16 +214,19 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 if (KNOWN && pos + ll > iend) err = -pos;            // never read literals past the source
                 // offset + match length from the same 16 bytes when they are all there
                 const int e = 3 + ll;                                // index of the first match-length byte (<= 14 when in_win)
-                const uint32_t extb = (uint32_t)((e < 8 ? lo >> (8 * (e & 7)) : hi >> (8 * (e & 7))) & 255u);
+                const uint32_t xe = e < 8 ? (e < 4 ? x0 : x1) : (e < 12 ? x2 : x3);
+                const uint32_t extb = (xe >> (8 * (e & 3))) & 255u;
                 // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
                 const bool fast = in_win && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
-                const int sh = 8 * ((1 + ll) & 15);                  // 8 .. 96 when in_win
-                const uint64_t vo = sh < 64 ? ((lo >> sh) | (hi << ((64 - sh) & 63))) : (hi >> (sh & 63));
+                const int o = 1 + ll, oq = o >> 2;                   // offset at bytes o, o+1 (o <= 12 when in_win)
+                const uint32_t xl = oq < 2 ? (oq == 0 ? x0 : x1) : (oq == 2 ? x2 : x3);
+                const uint32_t xh = oq < 2 ? (oq == 0 ? x1 : x2) : x3;
+                const uint32_t vo = wv::alignbyte(xh, xl, (uint32_t)o & 3u) & 0xFFFFu;
                 const int p_off = ip + 3 + ll;                       // after the offset
                 const int ml_fast = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
                 const int ip_fast = p_off + (mlc == 15u ? 1 : 0);
                 if (fast) {
-                    off = (int)(vo & 0xFFFFu);
+                    off = (int)vo;
                     ml = ml_fast;
                     if (err == 0 && lit_end - off < 0) err = -p_off;               // lz4.c:863 / :980
                     if (err == 0 && lit_end + ml > oend - kLastLiterals) err = -ip_fast;   // lz4.c:893 / :1024
@@ -203,13 +242,13 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             bool have = false;
             if (win_ok) {
                 const int d = ip - win_pos;
-                const bool up = d >= 8;
-                const uint64_t x0 = up ? w1 : w0, x1 = up ? w2 : w1;
-                const int sw = 8 * (d & 7);
-                const uint64_t lo = sw ? (x0 >> sw) | (x1 << (64 - sw)) : x0;
-                off = (int)((uint32_t)lo & 0xFFFFu);
+                const bool q2 = (d & 8) != 0, q1 = (d & 4) != 0;
+                const uint32_t y0 = q2 ? w2 : w0, y1 = q2 ? w3 : w1, y2 = q2 ? w4 : w2;
+                const uint32_t z0 = q1 ? y1 : y0, z1 = q1 ? y2 : y1;
+                const uint32_t hx = wv::perm(z1, z0, PHASE_SEL(d));
+                off = (int)(hx & 0xFFFFu);
                 ml = (int)(token & 15u);
-                const uint32_t b = (uint32_t)(lo >> 16) & 255u;
+                const uint32_t b = (hx >> 16) & 255u;
                 if (ml != 15) have = true;
                 else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
             }
@@ -238,20 +277,20 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         if (err != 0) return err;
         if (rem == 0 && pend == kNeedMatch) {
             // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
-            // the 16-byte period of an offset < 8 match is built for every lane (straight-line) and kept if needed
-            const int osafe = (off >= 1 && off < 8) ? off : 1;
-            const int sp = op - osafe, ks = sp >> 3, ss = (sp & 7) * 8;
-            const uint64_t q0 = OUTQ(ks), q1 = OUTQ(ks + 1);
-            uint64_t pat = (ss ? (q0 >> ss) | (q1 << (64 - ss)) : q0) & ((1ull << (8 * osafe)) - 1ull);
-            pat |= pat << (8 * osafe);                               // period x2 (<= 56-bit shift)
-            pat |= osafe < 4 ? pat << (16 * osafe) : 0ull;           // x4 while it still fits
-            pat |= osafe < 2 ? pat << 32 : 0ull;                     // x8 for offset 1
-            // bytes 8..15 of the periodic stream: it also has period L8 = off * (8 / off) <= 8
-            const int l8 = (int)((0x76586880u >> (4 * osafe)) & 15u);    // off 1..7 -> 8,8,6,8,5,6,7
-            uint64_t pat_hi = l8 == 8 ? pat : (pat >> (8 * (8 - l8)));
-            pat_hi |= l8 == 8 ? 0ull : (pat_hi << (8 * l8));
+            // the 16-byte period of an offset < 8 match is built for every lane (straight-line) and kept if needed:
+            // 8 ring bytes from op - off, then stream byte b = source byte (b mod off) via the selector table
             const bool periodic = off >= 1 && off < 8;
-            cv = periodic ? pat : cv; cv2 = periodic ? pat_hi : cv2;
+            const int osafe = periodic ? off : 1;
+            const int sp = op - osafe, ks = sp >> 2;
+            const uint32_t sr = PHASE_SEL(sp);
+            const uint32_t r0 = RING(ks), r1 = RING(ks + 1), r2 = RING(ks + 2);
+            const uint32_t s0 = wv::perm(r1, r0, sr), s1 = wv::perm(r2, r1, sr);
+            const uint32_t* t = period_tab + 4 * osafe;
+            const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+            c0 = periodic ? wv::perm(s1, s0, t0) : c0;
+            c1 = periodic ? wv::perm(s1, s0, t1) : c1;
+            c2 = periodic ? wv::perm(s1, s0, t2) : c2;
+            c3 = periodic ? wv::perm(s1, s0, t3) : c3;
             const int l16 = 16 - (int)((0x24101000u >> (4 * osafe)) & 15u);   // off 1..7 -> 16,16,15,16,15,12,14
             // chunk size: a multiple of the period, or at most `off` when the source would overlap the chunk
             stride = periodic ? l16 : ((off >= 16 || off == 0) ? 16 : off);
@@ -266,45 +305,50 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         // (four back-to-back 16-byte stores fill whole 32/64-byte sectors: PMC showed 16-byte pieces issued
         //  iterations apart being written back to HBM as partial sectors, 2x the output bytes)
         if (op - flushed >= 64) {
-            const int kq = flushed >> 3;
+            const uint32_t* fp = ring + ((flushed >> 2) & (RW - 1)) * 64;   // 16 dwords, no wrap: flushed is a multiple of 64
             for (int j = 0; j < 4; j++) {
-                const uint64_t a = OUTQ(kq + 2 * j), b2 = OUTQ(kq + 2 * j + 1);
-                const Vec16 v16 = { { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32) } };
+                const Vec16 v16 = { { fp[(4 * j) * 64], fp[(4 * j + 1) * 64], fp[(4 * j + 2) * 64], fp[(4 * j + 3) * 64] } };
                 store_v16(dst + flushed + 16 * j, v16);
             }
             flushed += 64;
         }
 
         // =========================== (d) request the next 16 source bytes ===========================
-        // (consumed in the next iteration; a far source lies > OUT_BYTES - 16 behind op, the fetch reads 16 bytes
-        //  from op - off, and at most 63 + 27 bytes behind op are still unflushed)
+        // (consumed in the next iteration; a far source lies > kNearMax behind op, the fetch reads 16 bytes
+        //  from op - off, and at most 63 bytes behind op are still unflushed at this point)
         if (mode == kGlobal && gcount == 0 && rem > 0) {
             const Vec16 w = load_v16(gptr);
-            g0 = w.w[0] | ((uint64_t)w.w[1] << 32); g1 = w.w[2] | ((uint64_t)w.w[3] << 32);
-            gcount = 2; gptr += 16;
+            g0 = w.w[0]; g1 = w.w[1]; g2 = w.w[2]; g3 = w.w[3];
+            gcount = 1; gptr += 16;
         }
 
         if (final_run && rem == 0) {
             // ---- end of block: write out the last (< 96) bytes exactly ----
-            while (op - flushed >= 8) { store_u64(dst + flushed, OUTQ(flushed >> 3)); flushed += 8; }
+            while (op - flushed >= 4) { const uint32_t q = RING(flushed >> 2); __builtin_memcpy(dst + flushed, &q, 4); flushed += 4; }
             if (flushed < op) {
-                const uint64_t q = OUTQ(flushed >> 3);
+                const uint32_t q = RING(flushed >> 2);
                 for (int b = 0; flushed + b < op; b++) dst[flushed + b] = (uint8_t)(q >> (8 * b));
             }
             return result;
         }
     }
-#undef OUTQ
-#undef APPEND
+#undef RING
+#undef APPEND_HEAD
+#undef APPEND_TAIL
+#undef APPEND4
+#undef APPEND3
+#undef PHASE_SEL
 #undef SLIDE_WINDOW
 }
 
-// One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.  Dynamic LDS: 64 * OUT_BYTES.
+// One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
+// Dynamic LDS: chunked_lds_bytes(OUT_BYTES) = 64 rings + the period table.
 template <bool KNOWN, int OUT_BYTES>
 __global__ void __launch_bounds__(64) decode_chunked_kernel(Batch b, int filter)
 {
     LZ4HIP_DYN_LDS(lds);
     const int lane = (int)threadIdx.x;
+    chunked_init_period_table(lds, lane, OUT_BYTES);
     const int64_t blk = (int64_t)blockIdx.x * 64 + lane;
     if (blk >= b.n_blocks) return;
     const int src_len = batch_src_len(b, blk), out_size = batch_dst_cap(b, blk);

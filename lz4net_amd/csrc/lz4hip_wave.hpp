@@ -56,6 +56,11 @@ LZ4HIP_DEVICE void mem_sync()
 
 LZ4HIP_DEVICE void block_sync() { __syncthreads(); }
 
+// v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi, lo} (0..3 -> lo, 4..7 -> hi; 0x0C -> 0x00).
+LZ4HIP_DEVICE uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// v_alignbyte_b32: ({hi, lo} >> 8 * (n & 3)) truncated to 32 bits.
+LZ4HIP_DEVICE uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+
 LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 LZ4HIP_DEVICE int popc64(uint64_t m) { return __builtin_popcountll(m); }
 

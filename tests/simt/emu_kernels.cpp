@@ -71,11 +71,11 @@ void emu_decode_chunked(int known, const uint8_t* src, int64_t src_stride, const
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
     if (ring == 128) {
-        if (known) simt::launch(grid, block, 64 * 128, [=] { decode_chunked_kernel<true, 128>(b, filter); });
-        else       simt::launch(grid, block, 64 * 128, [=] { decode_chunked_kernel<false, 128>(b, filter); });
+        if (known) simt::launch(grid, block, chunked_lds_bytes(128), [=] { decode_chunked_kernel<true, 128>(b, filter); });
+        else       simt::launch(grid, block, chunked_lds_bytes(128), [=] { decode_chunked_kernel<false, 128>(b, filter); });
     } else {
-        if (known) simt::launch(grid, block, 64 * 256, [=] { decode_chunked_kernel<true, 256>(b, filter); });
-        else       simt::launch(grid, block, 64 * 256, [=] { decode_chunked_kernel<false, 256>(b, filter); });
+        if (known) simt::launch(grid, block, chunked_lds_bytes(256), [=] { decode_chunked_kernel<true, 256>(b, filter); });
+        else       simt::launch(grid, block, chunked_lds_bytes(256), [=] { decode_chunked_kernel<false, 256>(b, filter); });
     }
 }
 

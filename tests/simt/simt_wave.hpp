@@ -77,6 +77,22 @@ inline bool any(bool pred) { return ballot(pred) != 0; }
 inline void mem_sync() { simt::yield(simt::WAIT_WAVE, 140); }
 inline void block_sync() { simt::yield(simt::WAIT_BLOCK, 150); }
 
+inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t s = (sel >> (8 * b)) & 255u;
+        uint32_t byte;
+        if (s < 8) byte = (uint32_t)(v >> (8 * s)) & 255u;
+        else if (s == 0x0C) byte = 0;
+        else { simt::die("wv::perm() selector outside 0..7 / 0x0C", (int)s); byte = 0; }
+        r |= byte << (8 * b);
+    }
+    return r;
+}
+inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (n & 3u))); }
+
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
