@@ -35,7 +35,8 @@ namespace lz4hip {
 
 constexpr int kChunkedRingBytes = 128;     // per-lane output ring
 constexpr int kChunkedTableBytes = 128;    // byte-permute selectors of the periods 1..7, behind the 64 rings
-constexpr unsigned chunked_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + (unsigned)kChunkedTableBytes; }
+constexpr int kChunkedFlushBytes = 1024;   // 64 flush records {lane, flushed, dst pointer}, behind the table
+constexpr unsigned chunked_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + (unsigned)(kChunkedTableBytes + kChunkedFlushBytes); }
 
 // what the next chunk of a lane's current copy is made from (>= kSlowLit: rare byte-wise sources)
 enum ChunkMode { kIdle = 0, kReg = 1, kNear = 2, kGlobal = 3, kSlowLit = 4, kZeroOff = 5 };
@@ -55,11 +56,12 @@ LZ4HIP_DEVICE void chunked_init_period_table(unsigned char* lds, int lane, int r
     wv::mem_sync();
 }
 
+// All 64 lanes of the wavefront call this together and stay in the loop until the last one is done: a lane
+// without a block (`active` false) or with a finished block still lends a hand to the cooperative flush.
 template <bool KNOWN, int OUT_BYTES>
-LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8_t* __restrict__ src, int iend,
+LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
                                        uint8_t* dst, int oend)
 {
-    if (!KNOWN && iend == 0) return 0;                               // lz4.c:946 returns -(0)
     constexpr int RW = OUT_BYTES / 4;                                // ring dwords per lane
     static_assert(OUT_BYTES >= 128 && (OUT_BYTES & (OUT_BYTES - 1)) == 0, "ring: power of two, >= 128 bytes");
     // An append writes whole dwords, up to 19 bytes past its last byte; those land on ring bytes op-OUT_BYTES+19
@@ -67,6 +69,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     constexpr int kNearMax = OUT_BYTES - 20;                         // largest offset served from the ring
     uint32_t* ring = (uint32_t*)lds + lane;                          // dword k of this lane at ring[(k & (RW-1)) * 64]
     const uint32_t* period_tab = (const uint32_t*)(lds + 64 * OUT_BYTES);
+    Vec16* flush_rec = (Vec16*)(lds + 64 * OUT_BYTES + kChunkedTableBytes);
 #define RING(k) ring[((k) & (RW - 1)) * 64]
 
     // ---- per-lane state (plain integers: bools would live in SGPR lane masks and cost s_and/s_or traffic) ----
@@ -86,6 +89,8 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
     int pend = kNeedToken;
     uint32_t token = 0;
     int final_run = 0, result = 0;
+    int done = 0;                // block finished (result holds the return value); the lane only helps flushing from now on
+    if (!active || (!KNOWN && iend == 0)) { done = 1; final_run = 1; }   // lz4.c:946 returns -(0)
 
     // Append the low n_ bytes of the data dwords to the output ring at op.  The data is rotated to the byte
     // phase of op with one v_perm_b32 per dword and stored as whole dwords; only the first dword is merged
@@ -138,7 +143,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
         } else win_ok = 0;                                                                              \
     } while (0)
 
-    SLIDE_WINDOW(0);
+    if (!done) SLIDE_WINDOW(0);
 
     for (;;) {
         // =========================== (b) one chunk (<= 16 bytes) of the current copy ===========================
@@ -189,7 +194,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 pos = ip + 1;
                 if (ll == 15) {
                     uint32_t b = 255;
-                    if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) return -pos; } while (b == 255); }
+                    if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) { err = -pos; ll = 0; break; } } while (b == 255); }
                     else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
                 }
             }
@@ -206,12 +211,12 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             rem = in_win ? 0 : ll;
             mode = rem ? lit_mode : (int)kIdle;
             if (last) {                                              // rare: final literal run, lz4.c:851-858 / :965-975
-                if (KNOWN) { if (lit_end != oend || pos + ll > iend) err = -pos; }
+                if (KNOWN) { if (err == 0 && (lit_end != oend || pos + ll > iend)) err = -pos; }
                 else       { if (lit_end > oend || pos + ll != iend) err = -pos; }
                 final_run = 1;
                 result = KNOWN ? pos + ll : lit_end;
             } else {
-                if (KNOWN && pos + ll > iend) err = -pos;            // never read literals past the source
+                if (KNOWN && err == 0 && pos + ll > iend) err = -pos;   // never read literals past the source
                 // offset + match length from the same 16 bytes when they are all there
                 const int e = 3 + ll;                                // index of the first match-length byte (<= 14 when in_win)
                 const uint32_t xe = e < 8 ? (e < 4 ? x0 : x1) : (e < 12 ? x2 : x3);
@@ -260,7 +265,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 if (ml == 15) {
                     if (KNOWN) {
                         uint32_t b;
-                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
+                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) { err = -p; break; } }
                         ml += (int)b; p++;
                     } else {
                         while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
@@ -268,13 +273,17 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
                 }
             }
             ml += kMinMatch;
-            if (op - off < 0) err = -(ip + 2);
+            if (err != 0) {}
+            else if (op - off < 0) err = -(ip + 2);
             else if (op + ml > oend - kLastLiterals) err = -p;
             ip = p;
             pend = kNeedMatch;
             SLIDE_WINDOW(ip);
         }
-        if (err != 0) return err;
+        if (err != 0) {                                              // corrupt stream: this lane is finished, nothing more is stored
+            done = 1; final_run = 1; result = err;
+            rem = 0; mode = kIdle; pend = kNeedToken;
+        }
         if (rem == 0 && pend == kNeedMatch) {
             // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
             // the 16-byte period of an offset < 8 match is built for every lane (straight-line) and kept if needed:
@@ -301,16 +310,37 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             pend = kNeedToken;
         }
 
-        // =========================== (c) flush finished output, 64 bytes at a time ===========================
-        // (four back-to-back 16-byte stores fill whole 32/64-byte sectors: PMC showed 16-byte pieces issued
-        //  iterations apart being written back to HBM as partial sectors, 2x the output bytes)
-        if (op - flushed >= 64) {
-            const uint32_t* fp = ring + ((flushed >> 2) & (RW - 1)) * 64;   // 16 dwords, no wrap: flushed is a multiple of 64
-            for (int j = 0; j < 4; j++) {
-                const Vec16 v16 = { { fp[(4 * j) * 64], fp[(4 * j + 1) * 64], fp[(4 * j + 2) * 64], fp[(4 * j + 3) * 64] } };
-                store_v16(dst + flushed + 16 * j, v16);
+        // =========================== (c) flush finished output, 64 bytes at a time, four lanes per line ===========================
+        // (one lane storing its own 4 x 16 bytes makes every store instruction touch 64 different lines; measured
+        //  ~12 CU-cycles per lane and store (tools/microbench_grouped.hip) -- the largest single cost of this kernel.
+        //  Instead lanes with 64 finished bytes publish {lane, flushed, dst}; lanes 4m..4m+3 then store the line of
+        //  the m-th publisher, 16 full 64-byte lines per store instruction.)
+        {
+            const bool need = !done && op - flushed >= 64;
+            const uint64_t needy = wv::ballot(need);
+            if (needy != 0) {                                        // wave-uniform
+                const int cnt = wv::popc64(needy);
+                if (need) {
+                    const uint64_t dp = (uint64_t)dst;
+                    flush_rec[wv::rank_below(needy)] = Vec16{ { (uint32_t)lane, (uint32_t)flushed, (uint32_t)dp, (uint32_t)(dp >> 32) } };
+                }
+                wv::mem_sync();
+                const int sub = lane & 3;
+                for (int base = 0; base < cnt; base += 16) {         // wave-uniform trip count, almost always 1
+                    const int idx = base + (lane >> 2);
+                    if (idx < cnt) {
+                        const Vec16 r = flush_rec[idx];
+                        const int fj = (int)r.w[1];
+                        uint8_t* dj = (uint8_t*)((uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32));
+                        // 16 dwords of lane r.w[0]'s ring from fj (a multiple of 64: no wrap), this lane takes 4 of them
+                        const uint32_t* fp = (const uint32_t*)lds + r.w[0] + (((fj >> 2) & (RW - 1)) + 4 * sub) * 64;
+                        const Vec16 v16 = { { fp[0], fp[64], fp[128], fp[192] } };
+                        store_v16(dj + fj + 16 * sub, v16);
+                    }
+                }
+                wv::mem_sync();                                      // records and ring bytes are free to be overwritten again
+                flushed += need ? 64 : 0;
             }
-            flushed += 64;
         }
 
         // =========================== (d) request the next 16 source bytes ===========================
@@ -322,16 +352,18 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, const uint8
             gcount = 1; gptr += 16;
         }
 
-        if (final_run && rem == 0) {
+        if (final_run && rem == 0 && !done) {
             // ---- end of block: write out the last (< 96) bytes exactly ----
             while (op - flushed >= 4) { const uint32_t q = RING(flushed >> 2); __builtin_memcpy(dst + flushed, &q, 4); flushed += 4; }
             if (flushed < op) {
                 const uint32_t q = RING(flushed >> 2);
                 for (int b = 0; flushed + b < op; b++) dst[flushed + b] = (uint8_t)(q >> (8 * b));
             }
-            return result;
+            done = 1;
         }
+        if (!wv::any(done == 0)) break;                              // every lane of the wavefront is finished
     }
+    return result;
 #undef RING
 #undef APPEND_HEAD
 #undef APPEND_TAIL
@@ -350,10 +382,17 @@ __global__ void __launch_bounds__(64) decode_chunked_kernel(Batch b, int filter)
     const int lane = (int)threadIdx.x;
     chunked_init_period_table(lds, lane, OUT_BYTES);
     const int64_t blk = (int64_t)blockIdx.x * 64 + lane;
-    if (blk >= b.n_blocks) return;
-    const int src_len = batch_src_len(b, blk), out_size = batch_dst_cap(b, blk);
-    if (!block_selected(filter, src_len, out_size)) return;
-    b.result[blk] = chunked_decode_block<KNOWN, OUT_BYTES>(lds, lane, batch_src(b, blk), src_len, batch_dst(b, blk), out_size);
+    bool active = blk < b.n_blocks;
+    int src_len = 0, out_size = 0;
+    if (active) {
+        src_len = batch_src_len(b, blk); out_size = batch_dst_cap(b, blk);
+        active = block_selected(filter, src_len, out_size);
+    }
+    if (!wv::any(active)) return;
+    const uint8_t* src = active ? batch_src(b, blk) : nullptr;
+    uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
+    const int r = chunked_decode_block<KNOWN, OUT_BYTES>(lds, lane, active, src, src_len, dst, out_size);
+    if (active) b.result[blk] = r;
 }
 
 }  // namespace lz4hip

@@ -43,6 +43,8 @@ LZ4HIP_DEVICE uint32_t shuffle(uint32_t v, int src_lane) { return (uint32_t)__bu
 
 LZ4HIP_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
 LZ4HIP_DEVICE bool any(bool p) { return __ballot(p) != 0ull; }
+// number of set bits of a wave-uniform mask below this lane's bit (v_mbcnt_lo/hi)
+LZ4HIP_DEVICE int rank_below(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 // Orders this wave's earlier memory operations before its later ones as seen by the OTHER lanes of
 // the same wave.  The hardware already executes a wave's vector-memory instructions in order; this

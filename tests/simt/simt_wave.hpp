@@ -73,6 +73,7 @@ inline uint64_t ballot(bool pred)
     return m;
 }
 inline bool any(bool pred) { return ballot(pred) != 0; }
+inline int rank_below(uint64_t m) { return __builtin_popcountll(m & ((1ull << lane()) - 1ull)); }
 
 inline void mem_sync() { simt::yield(simt::WAIT_WAVE, 140); }
 inline void block_sync() { simt::yield(simt::WAIT_BLOCK, 150); }
