@@ -232,7 +232,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
         int ring = kChunkedRingBytes;
         if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
-        const unsigned lds = chunked_lds_bytes(ring);
+        const unsigned lds = 0;   // the kernel's LDS is static
 #define LZ4HIP_LAUNCH_CHUNKED(R)                                                                                      \
         do {                                                                                                          \
             if (known) hipLaunchKernelGGL((decode_chunked_kernel<true, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);   \
@@ -253,7 +253,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
         int ring = kStagedRingBytes;
         if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
-        const unsigned lds = chunked_lds_bytes(ring);
+        const unsigned lds = 64u * (unsigned)ring;
 #define LZ4HIP_LAUNCH_STAGED(R)                                                                                      \
         do {                                                                                                          \
             if (lds > 65536u) {                                                                                       \

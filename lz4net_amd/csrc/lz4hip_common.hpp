@@ -60,6 +60,8 @@ LZ4HIP_DEVICE bool block_selected(int filter, int src_len, int out_size)
 // these to single global_load/store_dword[xN] instructions).
 LZ4HIP_DEVICE uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 struct alignas(4) Vec16 { uint32_t w[4]; };
+struct alignas(16) Aligned16 { uint32_t w[4]; };                 // 16-byte aligned LDS records
+struct __attribute__((packed)) Packed16 { uint32_t w[4]; };      // 16 bytes at any address
 LZ4HIP_DEVICE Vec16 load_v16(const uint8_t* p) { Vec16 v; __builtin_memcpy(&v, p, 16); return v; }
 LZ4HIP_DEVICE void store_v16(uint8_t* p, const Vec16& v) { __builtin_memcpy(p, &v, 16); }
 

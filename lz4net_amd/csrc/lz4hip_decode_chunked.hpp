@@ -67,10 +67,13 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
     // An append writes whole dwords, up to 19 bytes past its last byte; those land on ring bytes op-OUT_BYTES+19
     // and older.  Everything younger must stay intact: ring sources (<= kNearMax back) and unflushed output (< 91 back).
     constexpr int kNearMax = OUT_BYTES - 20;                         // largest offset served from the ring
-    uint32_t* ring = (uint32_t*)lds + lane;                          // dword k of this lane at ring[(k & (RW-1)) * 64]
+    // dword k of this lane lives at LDS byte ((k & (RW-1)) << 8) | (lane << 2); RING_AT(p, j) is the dword j dwords
+    // after the one containing output byte p (two instructions per address: v_lshl_add_u32, v_and_or_b32)
+    const uint32_t lane4 = (uint32_t)lane << 2;
+    constexpr uint32_t kRingMask = (uint32_t)(RW - 1) << 8;
     const uint32_t* period_tab = (const uint32_t*)(lds + 64 * OUT_BYTES);
-    Vec16* flush_rec = (Vec16*)(lds + 64 * OUT_BYTES + kChunkedTableBytes);
-#define RING(k) ring[((k) & (RW - 1)) * 64]
+    Aligned16* flush_rec = (Aligned16*)(lds + 64 * OUT_BYTES + kChunkedTableBytes);
+#define RING_AT(p, j) (*(uint32_t*)(lds + (((((uint32_t)(p)) << 6) + 256u * (uint32_t)(j)) & kRingMask | lane4)))
 
     // ---- per-lane state (plain integers: bools would live in SGPR lane masks and cost s_and/s_or traffic) ----
     int ip = 0;                  // position of the next header to parse
@@ -80,8 +83,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
     int win_pos = 0, win_ok = 0;
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
     int stride = 16;             // bytes per chunk (16, a multiple of a short period, or the offset when source and chunk would overlap)
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // kReg: 16 bytes of the periodic stream of an offset < 8 match
-    uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;   // kGlobal: fetched source bytes
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // kReg: 16 bytes of the periodic stream of an offset < 8 match; kGlobal: fetched source bytes
     int gcount = 0;              // kGlobal: (g0..g3) hold the next chunk
     const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
     int lit_src = 0;             // kSlowLit: position of the next literal byte in src
@@ -97,33 +99,34 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
     // (with the bytes below op).  Bytes past n_ are junk that the next append overwrites.
 #define APPEND_HEAD()                                                                                   \
         const uint32_t sb_ = (uint32_t)op & 3u;                                                         \
-        const uint32_t s_ = 0x07060504u - sb_ * 0x01010101u;     /* byte b <- source byte 4 + b - sb */ \
+        /* byte b <- source byte 4 + b - sb: selector bytes (4-sb, 5-sb, 6-sb, 7-sb) */                 \
+        const uint32_t s_ = wv::alignbyte(0x08070605u, 0x04030201u, sb_ ^ 3u);                          \
         const uint32_t keep_ = (1u << (8u * sb_)) - 1u;                                                 \
-        const int k_ = op >> 2
+        const int k_ = op
 #define APPEND_TAIL(n_)                                                                                 \
         op += (n_);                                                                                     \
-        tail = RING(op >> 2)
+        tail = RING_AT(op, 0)
 #define APPEND4(d0_, d1_, d2_, d3_, n_)                                                                 \
     do {                                                                                                \
         APPEND_HEAD();                                                                                  \
-        RING(k_) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
-        RING(k_ + 1) = wv::perm(d1_, d0_, s_);                                                          \
-        RING(k_ + 2) = wv::perm(d2_, d1_, s_);                                                          \
-        RING(k_ + 3) = wv::perm(d3_, d2_, s_);                                                          \
-        RING(k_ + 4) = wv::perm(0u, d3_, s_);                                                           \
+        RING_AT(k_, 0) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
+        RING_AT(k_, 1) = wv::perm(d1_, d0_, s_);                                                          \
+        RING_AT(k_, 2) = wv::perm(d2_, d1_, s_);                                                          \
+        RING_AT(k_, 3) = wv::perm(d3_, d2_, s_);                                                          \
+        RING_AT(k_, 4) = wv::perm(0u, d3_, s_);                                                           \
         APPEND_TAIL(n_);                                                                                \
     } while (0)
 #define APPEND3(d0_, d1_, d2_, n_)                                                                      \
     do {                                                                                                \
         APPEND_HEAD();                                                                                  \
-        RING(k_) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
-        RING(k_ + 1) = wv::perm(d1_, d0_, s_);                                                          \
-        RING(k_ + 2) = wv::perm(d2_, d1_, s_);                                                          \
-        RING(k_ + 3) = wv::perm(0u, d2_, s_);                                                           \
+        RING_AT(k_, 0) = (tail & keep_) | wv::perm(d0_, 0u, s_);                                              \
+        RING_AT(k_, 1) = wv::perm(d1_, d0_, s_);                                                          \
+        RING_AT(k_, 2) = wv::perm(d2_, d1_, s_);                                                          \
+        RING_AT(k_, 3) = wv::perm(0u, d2_, s_);                                                           \
         APPEND_TAIL(n_);                                                                                \
     } while (0)
     // selector that extracts 4 bytes at byte phase (p & 3) from a dword pair: wv::perm(hi, lo, PHASE_SEL(p))
-#define PHASE_SEL(p_) (0x03020100u + ((uint32_t)(p_) & 3u) * 0x01010101u)
+#define PHASE_SEL(p_) wv::alignbyte(0x07060504u, 0x03020100u, (uint32_t)(p_) & 3u)
 
     // Slide the window so that it covers [pos, pos + 16): usually nothing to do (a 16-byte load serves
     // ~3 short sequences); crossing into the second half shifts it and requests the next 16 bytes.
@@ -148,17 +151,16 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
     for (;;) {
         // =========================== (b) one chunk (<= 16 bytes) of the current copy ===========================
         {
+            // ring source (read unconditionally; only used by kNear)
+            const int sp = op - off;
+            uint32_t r0 = RING_AT(sp, 0), r1 = RING_AT(sp, 1), r2 = RING_AT(sp, 2), r3 = RING_AT(sp, 3), r4 = RING_AT(sp, 4);
+            const uint32_t sr = PHASE_SEL(sp);
             const bool can = rem > 0 && !(mode == kGlobal && gcount == 0);
             int n = can ? (rem < stride ? rem : stride) : 0;
-            // ring source (read unconditionally; only used by kNear)
-            const int sp = op - off, ks = sp >> 2;
-            const uint32_t sr = PHASE_SEL(sp);
-            const uint32_t r0 = RING(ks), r1 = RING(ks + 1), r2 = RING(ks + 2), r3 = RING(ks + 3), r4 = RING(ks + 4);
-            uint32_t v0 = wv::perm(r1, r0, sr), v1 = wv::perm(r2, r1, sr), v2 = wv::perm(r3, r2, sr), v3 = wv::perm(r4, r3, sr);
-            v0 = mode == kReg ? c0 : (mode == kGlobal ? g0 : v0);
-            v1 = mode == kReg ? c1 : (mode == kGlobal ? g1 : v1);
-            v2 = mode == kReg ? c2 : (mode == kGlobal ? g2 : v2);
-            v3 = mode == kReg ? c3 : (mode == kGlobal ? g3 : v3);
+            LZ4HIP_KEEP(r0); LZ4HIP_KEEP(r1); LZ4HIP_KEEP(r2); LZ4HIP_KEEP(r3); LZ4HIP_KEEP(r4);
+            const bool near = mode == kNear;
+            uint32_t v0 = near ? wv::perm(r1, r0, sr) : c0, v1 = near ? wv::perm(r2, r1, sr) : c1;
+            uint32_t v2 = near ? wv::perm(r3, r2, sr) : c2, v3 = near ? wv::perm(r4, r3, sr) : c3;
             if (mode >= kSlowLit && can) {                           // rare byte-wise sources, 8 bytes at a time
                 n = n < 8 ? n : 8;
                 uint64_t acc = 0;
@@ -219,14 +221,13 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                 if (KNOWN && err == 0 && pos + ll > iend) err = -pos;   // never read literals past the source
                 // offset + match length from the same 16 bytes when they are all there
                 const int e = 3 + ll;                                // index of the first match-length byte (<= 14 when in_win)
-                const uint32_t xe = e < 8 ? (e < 4 ? x0 : x1) : (e < 12 ? x2 : x3);
-                const uint32_t extb = (xe >> (8 * (e & 3))) & 255u;
-                // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
-                const bool fast = in_win && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
-                const int o = 1 + ll, oq = o >> 2;                   // offset at bytes o, o+1 (o <= 12 when in_win)
+                const int o = 1 + ll, oq = o >> 2;                   // offset at bytes o, o+1 (o <= 12 when in_win), length byte at o+2
                 const uint32_t xl = oq < 2 ? (oq == 0 ? x0 : x1) : (oq == 2 ? x2 : x3);
                 const uint32_t xh = oq < 2 ? (oq == 0 ? x1 : x2) : x3;
-                const uint32_t vo = wv::alignbyte(xh, xl, (uint32_t)o & 3u) & 0xFFFFu;
+                const uint32_t ot = wv::alignbyte(xh, xl, (uint32_t)o & 3u);   // bytes o .. o+3
+                const uint32_t vo = ot & 0xFFFFu, extb = (ot >> 16) & 255u;
+                // (the unknown-size decoder only reads a match-length byte while p < iend - 6, lz4.c:986)
+                const bool fast = in_win && (mlc != 15u || (extb != 255u && (KNOWN || ip + e < iend - (kLastLiterals + 1))));
                 const int p_off = ip + 3 + ll;                       // after the offset
                 const int ml_fast = (int)mlc + kMinMatch + (mlc == 15u ? (int)extb : 0);
                 const int ip_fast = p_off + (mlc == 15u ? 1 : 0);
@@ -290,9 +291,9 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
             // 8 ring bytes from op - off, then stream byte b = source byte (b mod off) via the selector table
             const bool periodic = off >= 1 && off < 8;
             const int osafe = periodic ? off : 1;
-            const int sp = op - osafe, ks = sp >> 2;
+            const int sp = op - osafe;
             const uint32_t sr = PHASE_SEL(sp);
-            const uint32_t r0 = RING(ks), r1 = RING(ks + 1), r2 = RING(ks + 2);
+            const uint32_t r0 = RING_AT(sp, 0), r1 = RING_AT(sp, 1), r2 = RING_AT(sp, 2);
             const uint32_t s0 = wv::perm(r1, r0, sr), s1 = wv::perm(r2, r1, sr);
             const uint32_t* t = period_tab + 4 * osafe;
             const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
@@ -322,20 +323,19 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                 const int cnt = wv::popc64(needy);
                 if (need) {
                     const uint64_t dp = (uint64_t)dst;
-                    flush_rec[wv::rank_below(needy)] = Vec16{ { (uint32_t)lane, (uint32_t)flushed, (uint32_t)dp, (uint32_t)(dp >> 32) } };
+                    flush_rec[wv::rank_below(needy)] = Aligned16{ { (uint32_t)lane, (uint32_t)flushed, (uint32_t)dp, (uint32_t)(dp >> 32) } };
                 }
                 wv::mem_sync();
                 const int sub = lane & 3;
                 for (int base = 0; base < cnt; base += 16) {         // wave-uniform trip count, almost always 1
                     const int idx = base + (lane >> 2);
                     if (idx < cnt) {
-                        const Vec16 r = flush_rec[idx];
+                        const Aligned16 r = flush_rec[idx];
                         const int fj = (int)r.w[1];
-                        uint8_t* dj = (uint8_t*)((uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32));
+                        const uint64_t dj = (uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32);
                         // 16 dwords of lane r.w[0]'s ring from fj (a multiple of 64: no wrap), this lane takes 4 of them
-                        const uint32_t* fp = (const uint32_t*)lds + r.w[0] + (((fj >> 2) & (RW - 1)) + 4 * sub) * 64;
-                        const Vec16 v16 = { { fp[0], fp[64], fp[128], fp[192] } };
-                        store_v16(dj + fj + 16 * sub, v16);
+                        const uint32_t* fp = (const uint32_t*)(lds + ((((uint32_t)fj << 6) & kRingMask) | (r.w[0] << 2))) + 4 * sub * 64;
+                        wv::store_global16(dj + (uint64_t)(fj + 16 * sub), fp[0], fp[64], fp[128], fp[192]);
                     }
                 }
                 wv::mem_sync();                                      // records and ring bytes are free to be overwritten again
@@ -348,15 +348,15 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
         //  from op - off, and at most 63 bytes behind op are still unflushed at this point)
         if (mode == kGlobal && gcount == 0 && rem > 0) {
             const Vec16 w = load_v16(gptr);
-            g0 = w.w[0]; g1 = w.w[1]; g2 = w.w[2]; g3 = w.w[3];
+            c0 = w.w[0]; c1 = w.w[1]; c2 = w.w[2]; c3 = w.w[3];
             gcount = 1; gptr += 16;
         }
 
         if (final_run && rem == 0 && !done) {
             // ---- end of block: write out the last (< 96) bytes exactly ----
-            while (op - flushed >= 4) { const uint32_t q = RING(flushed >> 2); __builtin_memcpy(dst + flushed, &q, 4); flushed += 4; }
+            while (op - flushed >= 4) { const uint32_t q = RING_AT(flushed, 0); __builtin_memcpy(dst + flushed, &q, 4); flushed += 4; }
             if (flushed < op) {
-                const uint32_t q = RING(flushed >> 2);
+                const uint32_t q = RING_AT(flushed, 0);
                 for (int b = 0; flushed + b < op; b++) dst[flushed + b] = (uint8_t)(q >> (8 * b));
             }
             done = 1;
@@ -364,7 +364,7 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
         if (!wv::any(done == 0)) break;                              // every lane of the wavefront is finished
     }
     return result;
-#undef RING
+#undef RING_AT
 #undef APPEND_HEAD
 #undef APPEND_TAIL
 #undef APPEND4
@@ -374,11 +374,11 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
-// Dynamic LDS: chunked_lds_bytes(OUT_BYTES) = 64 rings + the period table.
+// Static LDS: chunked_lds_bytes(OUT_BYTES) = 64 rings + the period table + the flush records.
 template <bool KNOWN, int OUT_BYTES>
 __global__ void __launch_bounds__(64) decode_chunked_kernel(Batch b, int filter)
 {
-    LZ4HIP_DYN_LDS(lds);
+    LZ4HIP_STATIC_LDS(lds, chunked_lds_bytes(OUT_BYTES));
     const int lane = (int)threadIdx.x;
     chunked_init_period_table(lds, lane, OUT_BYTES);
     const int64_t blk = (int64_t)blockIdx.x * 64 + lane;

@@ -14,6 +14,11 @@
 #define LZ4HIP_DEVICE __device__ __forceinline__
 // Dynamic LDS of the current workgroup, 16-byte aligned (cdna guide, Guideline 17).
 #define LZ4HIP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// Statically sized LDS of the current workgroup: its address is a compile-time constant that folds into the
+// offset field of ds_* instructions (a dynamic array costs one v_add per computed address).
+#define LZ4HIP_STATIC_LDS(name, bytes) __shared__ __attribute__((aligned(16))) unsigned char name[bytes]
+// Forces `x` to be computed here (stops the compiler from sinking a load into a later conditional block).
+#define LZ4HIP_KEEP(x) asm volatile("" : "+v"(x))
 
 namespace wv {
 
@@ -60,8 +65,16 @@ LZ4HIP_DEVICE void block_sync() { __syncthreads(); }
 
 // v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi, lo} (0..3 -> lo, 4..7 -> hi; 0x0C -> 0x00).
 LZ4HIP_DEVICE uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-// v_alignbyte_b32: ({hi, lo} >> 8 * (n & 3)) truncated to 32 bits.
+// v_alignbyte_b32: ({hi, lo} >> 8 * n) truncated to 32 bits; callers keep n in 0..3.
 LZ4HIP_DEVICE uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+
+// 16-byte store to a GLOBAL address rebuilt from integers, any alignment (global_store_dwordx4, not flat_*).
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+LZ4HIP_DEVICE void store_global16(uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    u32x4_unaligned v = { a, b, c, d };
+    *(__attribute__((address_space(1))) u32x4_unaligned*)addr = v;
+}
 
 LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 LZ4HIP_DEVICE int popc64(uint64_t m) { return __builtin_popcountll(m); }

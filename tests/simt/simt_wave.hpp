@@ -7,6 +7,8 @@
 #define LZ4HIP_WAVE_API 1
 #define LZ4HIP_DEVICE inline
 #define LZ4HIP_DYN_LDS(name) unsigned char* name = simt::rt().lds.data()
+#define LZ4HIP_STATIC_LDS(name, bytes) unsigned char* name = simt::rt().lds.data()
+#define LZ4HIP_KEEP(x) ((void)0)
 
 namespace wv {
 
@@ -92,7 +94,17 @@ inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
     }
     return r;
 }
-inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (n & 3u))); }
+inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
+{
+    if (n > 3) simt::die("wv::alignbyte() shift outside 0..3 (hardware behaviour differs between ISA revisions)", (int)n);
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * n));
+}
+
+inline void store_global16(uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t v[4] = { a, b, c, d };
+    __builtin_memcpy((void*)addr, v, 16);
+}
 
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
