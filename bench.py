@@ -285,6 +285,48 @@ def main():
                 "roundtrip_ok": bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0,
             }
             del raw, comp, back
+        # ---- the HBM roof measured on this box (quote the 8 TB/s spec AND what a copy reaches) ----
+        torch.cuda.empty_cache()
+        words = (4 << 30) // 8
+        xa = torch.empty(words, dtype=torch.int64, device="cuda")
+        xb = torch.empty(words, dtype=torch.int64, device="cuda")
+        xa.fill_(1); xb.copy_(xa); torch.cuda.synchronize()
+        t_fill = min(event_ms(lambda: xa.fill_(2), torch) for _ in range(3))
+        t_copy = min(event_ms(lambda: xb.copy_(xa), torch) for _ in range(3))
+        extras["hbm_measured"] = {
+            "fill_GBps_write_only": round(words * 8 / (t_fill / 1e3) / 1e9, 1),
+            "copy_GBps_read_plus_write": round(2 * words * 8 / (t_copy / 1e3) / 1e9, 1),
+            "bytes": words * 8, "note": "torch fill_/copy_ of a 4 GiB buffer, best of 3 (the spec-sheet 8000 GB/s is what roofline.peak quotes)",
+        }
+        del xa, xb
+        torch.cuda.empty_cache()
+        # ---- PCIe-inclusive rate of the host-pointer batch entry point (never `value`) ----
+        import ctypes as C
+        import numpy as np
+        m = min(4096, n)
+        raw_d = batch.synth(args.dist, seed, 0, m)
+        comp_d = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+        clen_h = batch.encode(raw_d, batch.BLOCK, comp_d, batch.BOUND).cpu().numpy().astype(np.int32)
+        comp_h, raw_h = comp_d.cpu().numpy(), raw_d.cpu().numpy()
+        back_h = np.zeros_like(raw_h)
+        caps_h = np.full(m, batch.BLOCK, np.int32)
+        res_h = np.zeros(m, np.int32)
+        hb = _lib.Batch(src=comp_h.ctypes.data, src_off=None, src_stride=comp_h.strides[0], src_len=clen_h.ctypes.data,
+                        dst=back_h.ctypes.data, dst_off=None, dst_stride=back_h.strides[0], dst_cap=caps_h.ctypes.data,
+                        dst_cap_all=0, src_len_all=0, result=res_h.ctypes.data, n_blocks=m)
+        _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
+        t_host = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
+            dt = time.perf_counter() - t1
+            t_host = dt if t_host is None else min(t_host, dt)
+        extras["host_pointer_batch_pcie_inclusive"] = {
+            "decode_GBps": round(m * batch.BLOCK / t_host / 1e9, 2), "blocks": m,
+            "ok": bool((res_h == clen_h).all()) and bool(np.array_equal(back_h, raw_h)),
+            "note": "lz4hip_decode_batch_host on pageable host arrays: H2D + kernel + D2H, best of 3 (reported beside, never as, `value`)",
+        }
+        del raw_d, comp_d
 
     if rank != 0:
         if world > 1:

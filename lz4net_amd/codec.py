@@ -232,3 +232,66 @@ class LZ4Codec(metaclass=_LZ4CodecMeta):
         result = np.zeros(output_length, dtype=np.uint8)
         cls._service.Decode(buf, inputOffset + 8, input_length, result, 0, output_length, True)
         return bytes(result)
+
+    # ---- batched Wrap / Unwrap (SURVEY.md 8f-2): many messages, ONE GPU batch ---------------------------
+    @classmethod
+    def WrapMany(cls, messages, high_compression: bool = False) -> list:
+        """[Wrap(m) for m in messages] with every message compressed in one lz4hip_encode_batch_host call."""
+        import ctypes as C
+        from . import _lib
+        from .stream import _batch
+        bufs = [bytes(_as_bytes(m, "inputBuffer")) for m in messages]
+        idx = [i for i, m in enumerate(bufs) if len(m) > 0]
+        out = [bytes(8)] * len(bufs)                                 # empty message -> 8 zero bytes (:497-498)
+        if not idx:
+            return out
+        lens = np.array([len(bufs[i]) for i in idx], dtype=np.int32)
+        offs = np.concatenate(([0], np.cumsum(lens[:-1], dtype=np.int64))).astype(np.int64)
+        raw = np.frombuffer(b"".join(bufs[i] for i in idx), dtype=np.uint8)
+        comp = np.zeros(raw.size, dtype=np.uint8)                    # outputLength = inputLength per message
+        res = np.zeros(len(idx), dtype=np.int32)
+        b = _batch(raw, offs, lens, comp, offs, lens, res)
+        _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), _lib.MODE_HC if high_compression else _lib.MODE_FAST))
+        for j, i in enumerate(idx):
+            ln, n, o = int(lens[j]), int(res[j]), int(offs[j])
+            if n >= ln or n <= 0:                                    # stored raw (:527-533)
+                out[i] = ln.to_bytes(4, "little") * 2 + bufs[i]
+            else:
+                out[i] = ln.to_bytes(4, "little") + n.to_bytes(4, "little") + comp[o:o + n].tobytes()
+        return out
+
+    @classmethod
+    def UnwrapMany(cls, wrapped) -> list:
+        """[Unwrap(w) for w in wrapped] with every compressed message decoded in one lz4hip_decode_batch_host call."""
+        import ctypes as C
+        from . import _lib
+        from .stream import _batch
+        bufs = [bytes(_as_bytes(w, "inputBuffer")) for w in wrapped]
+        out, todo = [None] * len(bufs), []
+        for i, w in enumerate(bufs):
+            if len(w) < 8:
+                raise ArgumentException("inputBuffer size is invalid")
+            olen = int.from_bytes(w[0:4], "little", signed=True)
+            ilen = int.from_bytes(w[4:8], "little", signed=True)
+            if ilen > len(w) - 8:
+                raise ArgumentException("inputBuffer size is invalid or has been corrupted")
+            if ilen >= olen:
+                out[i] = w[8:8 + ilen]
+            else:
+                todo.append((i, olen, ilen))
+        if todo:
+            src = np.frombuffer(b"".join(bufs[i][8:8 + il] for i, _, il in todo), dtype=np.uint8)
+            src_len = np.array([il for _, _, il in todo], dtype=np.int32)
+            dst_len = np.array([ol for _, ol, _ in todo], dtype=np.int32)
+            src_off = np.concatenate(([0], np.cumsum(src_len[:-1], dtype=np.int64))).astype(np.int64)
+            dst_off = np.concatenate(([0], np.cumsum(dst_len[:-1], dtype=np.int64))).astype(np.int64)
+            dst = np.zeros(int(dst_len.astype(np.int64).sum()), dtype=np.uint8)
+            res = np.zeros(len(todo), dtype=np.int32)
+            b = _batch(src, src_off, src_len, dst, dst_off, dst_len, res)
+            _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(b), 1))
+            if not (res == src_len).all():                           # Decode64: consumed != inputLength (Unsafe.cs:373-378)
+                raise ArgumentException("LZ4 block is corrupted, or invalid length has been given.")
+            for j, (i, ol, _) in enumerate(todo):
+                out[i] = dst[int(dst_off[j]):int(dst_off[j]) + ol].tobytes()
+        return out
+

@@ -20,7 +20,9 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace lz4hip;
@@ -293,7 +295,45 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Pinned (page-locked) host staging, grow-only, per calling thread: two slots so that the host can fill / drain
+// one slice while the device works on the other.
+struct Pinned {
+    void* p = nullptr; size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = n < (1u << 20) ? (1u << 20) : n;
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    ~Pinned() { /* see ~Scratch */ }
+};
+thread_local Pinned g_pin_in[2], g_pin_out[2];
+
+// f(i) for i in [0, n): on the calling thread for small jobs, on up to 8 threads for large ones (row gathers and
+// scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
+template <class F>
+void for_rows(int64_t n, size_t bytes, F f)
+{
+    unsigned t = std::thread::hardware_concurrency();
+    t = t > 8 ? 8 : t;
+    if (bytes < (8u << 20) || n < 2 || t < 2) { for (int64_t i = 0; i < n; i++) f(i); return; }
+    if ((int64_t)t > n) t = (unsigned)n;
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < t; k++) {
+        const int64_t lo = n * k / t, hi = n * (k + 1) / t;
+        pool.emplace_back([=] { for (int64_t i = lo; i < hi; i++) f(i); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 // Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
+// The batch is cut into slices of ~64 MiB; per slice: rows are gathered into pinned memory (host threads), ONE
+// host-to-device copy, the kernels, ONE device-to-host copy into pinned memory, rows scattered to the caller.
+// Everything of a slice is queued on the calling thread's stream; the host gathers slice k+1 and scatters
+// slice k-1 while the device is busy with slice k.
 template <class Run>
 int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 {
@@ -313,43 +353,83 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
         max_dst = dc > max_dst ? dc : max_dst;
     }
     const size_t s_stride = align_up((size_t)max_src + 16, 16), d_stride = align_up((size_t)max_dst + 16, 16);
-    const size_t o_src = 0, o_dst = align_up(o_src + s_stride * (size_t)n, 256),
-                 o_sl = align_up(o_dst + d_stride * (size_t)n, 256), o_dc = o_sl + align_up(4 * (size_t)n, 256),
-                 o_res = o_dc + align_up(4 * (size_t)n, 256), total = o_res + align_up(4 * (size_t)n, 256);
-    if ((rc = g_scratch.reserve(total))) return rc;
-    uint8_t* base = (uint8_t*)g_scratch.p;
+    int64_t per_slice = (int64_t)((64u << 20) / (s_stride + d_stride));
+    per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
+    const size_t m = (size_t)per_slice;
+    // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
+    const size_t in_lens = align_up(s_stride * m, 256), in_caps = in_lens + align_up(4 * m, 256), in_bytes = in_caps + align_up(4 * m, 256);
+    const size_t out_res = align_up(d_stride * m, 256), out_bytes = out_res + align_up(4 * m, 256);
+    if ((rc = g_scratch.reserve(in_bytes + out_bytes))) return rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = g_pin_in[k].reserve(in_bytes))) return rc;
+        if ((rc = g_pin_out[k].reserve(out_bytes))) return rc;
+    }
+    uint8_t* d_in = (uint8_t*)g_scratch.p;
+    uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = hipStreamPerThread;
+    hipEvent_t done[2];
+    HIP_TRY(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
 
-    std::vector<int32_t> sl((size_t)n), dc((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        sl[(size_t)i] = hb->src_len ? hb->src_len[i] : hb->src_len_all;
-        dc[(size_t)i] = hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all;
-        const uint8_t* s = (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride);
-        if (sl[(size_t)i] > 0)
-            HIP_TRY(hipMemcpyAsync(base + o_src + s_stride * (size_t)i, s, (size_t)sl[(size_t)i], hipMemcpyHostToDevice, stream));
+    auto src_row = [&](int64_t i) { return (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride); };
+    auto dst_row = [&](int64_t i) { return (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride); };
+    auto src_len = [&](int64_t i) { return hb->src_len ? hb->src_len[i] : hb->src_len_all; };
+    auto dst_cap = [&](int64_t i) { return hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all; };
+
+    // drain slice [first, first + cnt) from pinned slot `slot` into the caller's buffers
+    auto scatter = [&](int64_t first, int64_t cnt, int slot) {
+        const uint8_t* po = (const uint8_t*)g_pin_out[slot].p;
+        const int32_t* res = (const int32_t*)(po + out_res);
+        for (int64_t j = 0; j < cnt; j++) hb->result[first + j] = res[j];
+        for_rows(cnt, (size_t)cnt * d_stride, [&, po, res, first](int64_t j) {
+            // bytes the caller gets back: the result for encoders / unknown-size decode, the full size for known-size decode
+            const int32_t cap = dst_cap(first + j);
+            int64_t nbytes = dst_len_is_result ? res[j] : cap;
+            if (!dst_len_is_result && res[j] < 0) nbytes = 0;
+            if (nbytes > cap) nbytes = cap;
+            if (nbytes > 0) memcpy(dst_row(first + j), po + d_stride * (size_t)j, (size_t)nbytes);
+        });
+    };
+
+    int err = 0;
+    int64_t prev_first = 0, prev_cnt = 0;
+    int slice = 0;
+    for (int64_t first = 0; first < n && !err; first += per_slice, slice++) {
+        const int64_t cnt = n - first < per_slice ? n - first : per_slice;
+        const int slot = slice & 1;
+        // (slot was drained two iterations ago: its scatter ran synchronously below)
+        uint8_t* pi = (uint8_t*)g_pin_in[slot].p;
+        int32_t* lens = (int32_t*)(pi + in_lens);
+        int32_t* caps = (int32_t*)(pi + in_caps);
+        for (int64_t j = 0; j < cnt; j++) { lens[j] = src_len(first + j); caps[j] = dst_cap(first + j); }
+        for_rows(cnt, (size_t)cnt * s_stride, [&, pi, first](int64_t j) {
+            const int32_t sl = src_len(first + j);
+            if (sl > 0) memcpy(pi + s_stride * (size_t)j, src_row(first + j), (size_t)sl);
+        });
+        // the device image of the previous slice is still being read by its D2H copy: same stream, so ordered
+        if (hipMemcpyAsync(d_in, pi, in_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "H2D copy failed"); break; }
+        lz4hip_batch_t db;
+        db.src = d_in; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(d_in + in_lens);
+        db.dst = d_out; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(d_in + in_caps);
+        db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(d_out + out_res); db.n_blocks = cnt;
+        if ((err = run(&db, stream))) break;
+        if (hipMemcpyAsync(g_pin_out[slot].p, d_out, out_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipEventRecord(done[slot], stream) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "D2H copy failed"); break; }
+        if (prev_cnt) {                                              // drain the previous slice while this one runs
+            if (hipEventSynchronize(done[slot ^ 1]) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "device fault"); break; }
+            scatter(prev_first, prev_cnt, slot ^ 1);
+        }
+        prev_first = first; prev_cnt = cnt;
     }
-    HIP_TRY(hipMemcpyAsync(base + o_sl, sl.data(), 4 * (size_t)n, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(base + o_dc, dc.data(), 4 * (size_t)n, hipMemcpyHostToDevice, stream));
-
-    lz4hip_batch_t db;
-    db.src = base + o_src; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(base + o_sl);
-    db.dst = base + o_dst; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(base + o_dc);
-    db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(base + o_res); db.n_blocks = n;
-    if ((rc = run(&db, stream))) return rc;
-
-    HIP_TRY(hipMemcpyAsync(hb->result, base + o_res, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (int64_t i = 0; i < n; i++) {
-        // bytes the caller gets back: the result for encoders / unknown-size decode, the full size for known-size decode
-        int64_t nbytes = dst_len_is_result ? hb->result[i] : dc[(size_t)i];
-        if (!dst_len_is_result && hb->result[i] < 0) nbytes = 0;
-        if (nbytes <= 0) continue;
-        if (nbytes > dc[(size_t)i]) nbytes = dc[(size_t)i];
-        uint8_t* d = (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride);
-        HIP_TRY(hipMemcpyAsync(d, base + o_dst + d_stride * (size_t)i, (size_t)nbytes, hipMemcpyDeviceToHost, stream));
+    if (!err && prev_cnt) {
+        const int slot = (slice - 1) & 1;
+        if (hipEventSynchronize(done[slot]) != hipSuccess) err = fail(LZ4HIP_E_DEVICE, "device fault");
+        else scatter(prev_first, prev_cnt, slot);
     }
-    HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    if (err) (void)hipStreamSynchronize(stream);
+    (void)hipEventDestroy(done[0]);
+    (void)hipEventDestroy(done[1]);
+    return err;
 }
 
 int single(const char* src, int src_len, char* dst, int dst_cap, int kind /*0 fast,1 hc,2 dec known,3 dec unknown*/)
