@@ -176,6 +176,45 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
 
         // =========================== (a) header parsing ===========================
         int err = 0;                                                 // nonzero: this lane's stream is corrupt, value = return code
+        if (rem == 0 && pend == kNeedHeader) {
+            // ---- offset + match length at ip (after a literal run that did not fit the token's window) ----
+            int p = ip + 2;
+            bool have = false;
+            if (win_ok) {
+                const int d = ip - win_pos;
+                const bool q2 = (d & 8) != 0, q1 = (d & 4) != 0;
+                const uint32_t y0 = q2 ? w2 : w0, y1 = q2 ? w3 : w1, y2 = q2 ? w4 : w2;
+                const uint32_t z0 = q1 ? y1 : y0, z1 = q1 ? y2 : y1;
+                const uint32_t hx = wv::perm(z1, z0, PHASE_SEL(d));
+                off = (int)(hx & 0xFFFFu);
+                ml = (int)(token & 15u);
+                const uint32_t b = (hx >> 16) & 255u;
+                if (ml != 15) have = true;
+                else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
+            }
+            if (!have) {                                             // rare: byte-wise, lz4.c:862-866 / :979-997
+                p = ip;
+                off = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
+                p += 2;
+                ml = (int)(token & 15u);
+                if (ml == 15) {
+                    if (KNOWN) {
+                        uint32_t b;
+                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) { err = -p; break; } }
+                        ml += (int)b; p++;
+                    } else {
+                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
+                    }
+                }
+            }
+            ml += kMinMatch;
+            if (err != 0) {}
+            else if (op - off < 0) err = -(ip + 2);
+            else if (op + ml > oend - kLastLiterals) err = -p;
+            ip = p;
+            pend = kNeedMatch;
+            SLIDE_WINDOW(ip);
+        }
         if (rem == 0 && pend == kNeedToken && !final_run) {
             // ---- the 16 bytes at ip, from the window: dword shift network + one byte permute per dword ----
             const int d = ip - win_pos;
@@ -241,45 +280,6 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                 ip = fast ? ip_fast : pos + ll;
                 SLIDE_WINDOW(ip);                                    // a needed load travels while this sequence is copied
             }
-        }
-        if (rem == 0 && pend == kNeedHeader && err == 0) {
-            // ---- offset + match length at ip (after a literal run that did not fit the token's window) ----
-            int p = ip + 2;
-            bool have = false;
-            if (win_ok) {
-                const int d = ip - win_pos;
-                const bool q2 = (d & 8) != 0, q1 = (d & 4) != 0;
-                const uint32_t y0 = q2 ? w2 : w0, y1 = q2 ? w3 : w1, y2 = q2 ? w4 : w2;
-                const uint32_t z0 = q1 ? y1 : y0, z1 = q1 ? y2 : y1;
-                const uint32_t hx = wv::perm(z1, z0, PHASE_SEL(d));
-                off = (int)(hx & 0xFFFFu);
-                ml = (int)(token & 15u);
-                const uint32_t b = (hx >> 16) & 255u;
-                if (ml != 15) have = true;
-                else if (b != 255u && (KNOWN || p < iend - (kLastLiterals + 1))) { ml += (int)b; p++; have = true; }
-            }
-            if (!have) {                                             // rare: byte-wise, lz4.c:862-866 / :979-997
-                p = ip;
-                off = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
-                p += 2;
-                ml = (int)(token & 15u);
-                if (ml == 15) {
-                    if (KNOWN) {
-                        uint32_t b;
-                        while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) { err = -p; break; } }
-                        ml += (int)b; p++;
-                    } else {
-                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
-                    }
-                }
-            }
-            ml += kMinMatch;
-            if (err != 0) {}
-            else if (op - off < 0) err = -(ip + 2);
-            else if (op + ml > oend - kLastLiterals) err = -p;
-            ip = p;
-            pend = kNeedMatch;
-            SLIDE_WINDOW(ip);
         }
         if (err != 0) {                                              // corrupt stream: this lane is finished, nothing more is stored
             done = 1; final_run = 1; result = err;

@@ -250,3 +250,44 @@ def test_lz4h_shaped_single_block_calls(gpu, oracle):
     back[:] = 0
     assert L.lz4hip_uncompress_unknownOutputSize(comp.ctypes.data, back.ctypes.data, len(want), a.size) == a.size
     assert np.array_equal(back, a)
+
+
+def test_host_batch_many_slices_and_layouts(gpu, oracle):
+    """The host-pointer entry points cut a batch into ~64 MiB slices staged through pinned memory (gather/scatter on
+    host threads): a batch spanning several slices, with ragged and empty rows and an offset-addressed (packed) layout,
+    must give exactly what the oracle gives block by block."""
+    import ctypes as C
+    from lz4net_amd import _lib
+    rng = np.random.default_rng(17)
+    n = 2600                                                     # ~170 MiB of input -> several slices each way
+    sizes = rng.integers(0, 65537, n)
+    sizes[:8] = [0, 1, 12, 13, 65536, 65535, 64, 4096]
+    raw_rows = oracle.gen(2, 99, 0, n)
+    # packed source: block i at src_off[i], lengths ragged
+    src_off = np.concatenate(([0], np.cumsum(sizes[:-1]))).astype(np.int64)
+    src = np.concatenate([raw_rows[i, :sizes[i]] for i in range(n)] + [np.zeros(16, np.uint8)])
+    lens = sizes.astype(np.int32)
+    caps = np.array([int(s) + int(s) // 255 + 16 for s in sizes], np.int32)
+    dst_off = np.concatenate(([0], np.cumsum(caps[:-1].astype(np.int64)))).astype(np.int64)
+    dst = np.full(int(caps.astype(np.int64).sum()) + 64, 0xA5, np.uint8)
+    res = np.zeros(n, np.int32)
+    b = _lib.Batch(src=src.ctypes.data, src_off=src_off.ctypes.data, src_stride=0, src_len=lens.ctypes.data,
+                   dst=dst.ctypes.data, dst_off=dst_off.ctypes.data, dst_stride=0, dst_cap=caps.ctypes.data,
+                   dst_cap_all=0, src_len_all=0, result=res.ctypes.data, n_blocks=n)
+    _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), 0))
+    for i in list(range(16)) + list(range(16, n, 97)) + [n - 1]:
+        ret, out = oracle.compress_raw(raw_rows[i, :sizes[i]], int(caps[i]))
+        assert res[i] == ret, i
+        assert bytes(dst[dst_off[i]:dst_off[i] + ret]) == bytes(out[:ret]), i
+    assert (dst[-64:] == 0xA5).all()
+    # decode the packed compressed rows back into a strided destination, known sizes
+    back = np.full((n, 65536 + 32), 0x5A, np.uint8)
+    used = np.zeros(n, np.int32)
+    d = _lib.Batch(src=dst.ctypes.data, src_off=dst_off.ctypes.data, src_stride=0, src_len=res.ctypes.data,
+                   dst=back.ctypes.data, dst_off=None, dst_stride=back.strides[0], dst_cap=lens.ctypes.data,
+                   dst_cap_all=0, src_len_all=0, result=used.ctypes.data, n_blocks=n)
+    _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(d), 1))
+    assert (used == res).all()
+    for i in range(n):
+        assert np.array_equal(back[i, :sizes[i]], raw_rows[i, :sizes[i]]), i
+        assert (back[i, sizes[i]:] == 0x5A).all(), i
