@@ -144,7 +144,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
             int64_t groups = (int64_t)cus * wpc;
             if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-            const size_t per_lane = pick == 's' ? (size_t)kSmTableBytes : (size_t)kFastTableBytes;
+            const size_t per_lane = pick == 's' ? (size_t)kSmTableBytes : (size_t)kLaneTableBytes;
             void* ws = nullptr;
             int rc = workspace(g_fast_ws, (size_t)groups * 64 * per_lane + 256, &ws);
             if (rc) return rc;

@@ -20,6 +20,55 @@
 namespace lz4hip {
 
 constexpr int kLaneEncodeWavesPerCu = 16;
+constexpr int kLaneTableBytes = 32768;      // per lane: tagged u32[8192] (64k variant) or u32[4096] (generic variant)
+
+// The hash table of one block as this mapping keeps it.  What the algorithm sees is exactly the reference's table
+// (bucket -> last position inserted, empty bucket == position 0, lz4.c:583,642-651); the 64k variant additionally
+// keeps 15 more bits of the inserted sequence's hash product next to the position.  Two sequences with different
+// tags cannot be equal, so most failing probes are decided without touching the input at the candidate position --
+// one scattered memory request less per probe, and scattered requests are what bounds this kernel.
+template <bool GENERIC> struct LaneTable;
+template <> struct LaneTable<true> {        // U32 HashTable[4096], positions as they are
+    uint32_t* t; const uint8_t* in;
+    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input)
+    {
+        t = (uint32_t*)bytes; in = input;
+        for (int k = 0; k < kFastTableBytes; k += 16) store_v16(bytes + k, Vec16{ { 0, 0, 0, 0 } });
+    }
+    LZ4HIP_DEVICE void put(uint32_t word, int pos) { t[FastTable<true>::hash(word)] = (uint32_t)pos; }
+    // ref = table[h]; table[h] = pos; returns whether the 4 bytes at ref equal `word` (distance check included)
+    LZ4HIP_DEVICE bool exchange(uint32_t word, int pos, int& ref)
+    {
+        const uint32_t h = FastTable<true>::hash(word);
+        ref = (int)t[h];
+        t[h] = (uint32_t)pos;
+        if (ref < pos - kMaxDistance) return false;                   // lz4.c:427 / :538 (ref > ip - (MAX_DISTANCE + 1))
+        return load_u32(in + ref) == word;
+    }
+};
+template <> struct LaneTable<false> {       // U16 HashTable[8192] as (valid:1 | tag:15 | position:16)
+    uint32_t* t; const uint8_t* in; uint32_t word0;
+    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input)
+    {
+        t = (uint32_t*)bytes; in = input; word0 = load_u32(input);     // an empty bucket is position 0 (never inserted)
+        for (int k = 0; k < kLaneTableBytes; k += 16) store_v16(bytes + k, Vec16{ { 0, 0, 0, 0 } });
+    }
+    LZ4HIP_DEVICE void put(uint32_t word, int pos)
+    {
+        const uint32_t prod = word * kGolden;
+        t[prod >> 19] = 0x80000000u | (((prod >> 4) & 0x7FFFu) << 16) | (uint32_t)pos;
+    }
+    LZ4HIP_DEVICE bool exchange(uint32_t word, int pos, int& ref)
+    {
+        const uint32_t prod = word * kGolden, h = prod >> 19, tag = (prod >> 4) & 0x7FFFu;
+        const uint32_t e = t[h];
+        t[h] = 0x80000000u | (tag << 16) | (uint32_t)pos;
+        ref = (int)(e & 0xFFFFu);                                     // 0 for an empty bucket
+        if ((e >> 31) == 0) return word0 == word;
+        if (((e >> 16) & 0x7FFFu) != tag) return false;               // different sequences for certain
+        return load_u32(in + ref) == word;
+    }
+};
 
 // exact number of equal bytes in[a + i] == in[b + i] while a + i < limit (b < a)
 LZ4HIP_DEVICE int lane_count_equal(const uint8_t* __restrict__ in, int a, int b, int limit)
@@ -63,15 +112,12 @@ LZ4HIP_DEVICE int lane_put_length(uint8_t* out, int rest)
 template <bool GENERIC>
 LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, uint8_t* out, int cap, uint8_t* table_bytes)
 {
-    typedef FastTable<GENERIC> T;
-    typedef typename T::entry entry;
-    entry* table = (entry*)table_bytes;
+    LaneTable<GENERIC> table;
     const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
     int ip = 0, anchor = 0, op = 0;
 
     if (n >= kMinLength) {                                            // lz4.c:615
-        for (int k = 0; k < kFastTableBytes; k += 16) store_v16(table_bytes + k, Vec16{ { 0, 0, 0, 0 } });   // fresh table (lz4.c:583)
-        if (GENERIC) table[T::hash(load_u32(in))] = 0;                // lz4.c:403
+        table.clear(table_bytes, in);                                 // fresh table (lz4.c:583); generic: HashTable[hash(0)] = 0 (lz4.c:403) == the fill
         ip = 1;                                                       // lz4.c:631
         // 8-byte register window over the input for the (mostly sequential) forward reads of the search loop
         uint64_t fw = load_u64(in + ip);                              // n >= 13: in-bounds
@@ -87,17 +133,13 @@ LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, 
             bool out_of_input = false;
             for (;;) {
                 cur_word = fwd_word;
-                const uint32_t h = T::hash(cur_word);
                 const int step = attempts++ >> 6;
                 ip = probe;
                 probe = ip + step;
                 if (probe > mflimit) { out_of_input = true; break; }
                 FWD_REFILL(probe);
                 fwd_word = FWD_WORD(probe);
-                ref = (int)table[h];
-                table[h] = (entry)ip;
-                if (GENERIC && ref < ip - kMaxDistance) continue;     // lz4.c:427
-                if (load_u32(in + ref) == cur_word) break;
+                if (table.exchange(cur_word, ip, ref)) break;       // lz4.c:649-654 (generic: distance test of :427 inside)
             }
             if (out_of_input) break;
 
@@ -153,13 +195,9 @@ LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, 
                 if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
                 // ---- re-seed the table and test the next position: lz4.c:739-751 ----
                 fw_pos = ip - 2; fw = load_u64(in + fw_pos);           // ip <= mflimit: ip - 2 + 8 <= n
-                table[T::hash(FWD_WORD(ip - 2))] = (entry)(ip - 2);
+                table.put(FWD_WORD(ip - 2), ip - 2);
                 cur_word = FWD_WORD(ip);
-                const uint32_t h = T::hash(cur_word);
-                ref = (int)table[h];
-                table[h] = (entry)ip;
-                const bool in_range = !GENERIC || ref > ip - (kMaxDistance + 1);   // lz4.c:538
-                if (!(in_range && load_u32(in + ref) == cur_word)) break;
+                if (!table.exchange(cur_word, ip, ref)) break;       // lz4.c:743-751 (generic: distance test of :538 inside)
                 token_at = op++;                                      // zero-literal sequence (lz4.c:751)
                 token = 0; ll = 0;
                 packed = token_at + 16 <= cap;
@@ -184,10 +222,10 @@ tail:
 }
 
 // Persistent grid: every lane pulls block indices from `counter` until the batch is exhausted.
-// `tables` holds one 16 KiB hash table per lane of the grid.
+// `tables` holds kLaneTableBytes of hash table per lane of the grid.
 __global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables)
 {
-    uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kFastTableBytes;
+    uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLaneTableBytes;
     for (;;) {
         const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
         if (blk >= b.n_blocks) return;

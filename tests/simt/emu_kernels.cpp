@@ -107,7 +107,7 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     static std::vector<uint8_t> ws;
-    ws.assign(256 + (size_t)groups * 64 * kFastTableBytes, 0x5A);     // poisoned: the kernel must zero its tables
+    ws.assign(256 + (size_t)groups * 64 * kLaneTableBytes, 0x5A);     // poisoned: the kernel must zero its tables
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* tables = ws.data() + 256;
