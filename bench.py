@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--hc-blocks", type=int, default=1 << 16, help="blocks for the LZ4HC extra (0 = skip)")
+    ap.add_argument("--hc-blocks", type=int, default=1 << 18, help="blocks for the LZ4HC extra (SURVEY 8d C4: 2^18; 0 = skip)")
     ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
     ap.add_argument("--encoder", choices=["auto", "lane", "wave", "sm"], default="auto")
@@ -82,8 +82,11 @@ class Workload:
         self.back = torch.empty((n, batch.BLOCK + dst_pad), dtype=torch.uint8, device="cuda")
         self.used = torch.empty(n, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
-        # warm-up launch on a sliver (module load, LDS config), then the timed single-pass encode
+        # warm-up launches on slivers (module load; the lane encoder's per-device table workspace is allocated by
+        # the first batch of >= 16384 blocks), then the timed single-pass encode
         batch.encode(self.raw[:64], batch.BLOCK, self.comp[:64], batch.BOUND, result=self.clen[:64])
+        k = min(n, 16384)
+        batch.encode(self.raw[:k], batch.BLOCK, self.comp[:k], batch.BOUND, result=self.clen[:k])
         torch.cuda.synchronize()
         self.encode_ms = event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
         self.comp_bytes = int(self.clen.to(torch.int64).sum().item())
@@ -270,18 +273,26 @@ def main():
             torch.cuda.empty_cache()
         if args.hc_blocks > 0:
             m = min(args.hc_blocks, n)
+            free_b, total_b = torch.cuda.mem_get_info()
+            print(f"[bench] before LZ4HC: {free_b / 2**30:.1f} GiB free of {total_b / 2**30:.1f}", file=sys.stderr)
             raw = batch.synth(args.dist, seed, 0, m)
             comp = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
             batch.encode(raw[:64], batch.BLOCK, comp[:64], batch.BOUND, hc=True)
             torch.cuda.synchronize()
-            clen_holder = {}
-            ms = event_ms(lambda: clen_holder.setdefault("c", batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)), torch)
+            # two passes: the first one also allocates the per-device LZ4HC workspace (192 KiB per resident lane,
+            # a one-time cost per process); the rate quoted is the pass that finds it in place
+            ms_all = []
+            for _ in range(2):
+                clen_holder = {}
+                ms_all.append(event_ms(lambda: clen_holder.setdefault("c", batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)), torch))
+            ms = min(ms_all)
             clen = clen_holder["c"]
             back = torch.empty_like(raw)
             used = batch.decode(comp, clen, back, batch.BLOCK)
             extras["LZ4HC " + DIST_NAMES[args.dist]] = {
                 "encode_hc_GBps": round(m * batch.BLOCK / (ms / 1e3) / 1e9, 3),
                 "ratio": round(float(clen.double().sum().item()) / (m * batch.BLOCK), 4), "blocks": m,
+                "first_pass_with_workspace_allocation_GBps": round(m * batch.BLOCK / (ms_all[0] / 1e3) / 1e9, 3),
                 "roundtrip_ok": bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0,
             }
             del raw, comp, back
