@@ -84,7 +84,8 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
     int mode = kIdle, rem = 0;   // current copy: source kind and bytes left
     int stride = 16;             // bytes per chunk (16, a multiple of a short period, or the offset when source and chunk would overlap)
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // kReg: 16 bytes of the periodic stream of an offset < 8 match; kGlobal: fetched source bytes
-    int gcount = 0;              // kGlobal: (g0..g3) hold the next chunk
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;   // kGlobal: the 16 bytes after (c0..c3) when a copy of > 16 bytes was requested
+    int gcount = 0;              // kGlobal: fetched 16-byte pieces not yet consumed (0..2): c, then e
     const uint8_t* gptr = dst;   // kGlobal: where the next 16-byte fetch comes from
     int lit_src = 0;             // kSlowLit: position of the next literal byte in src
     int off = 8, ml = 0;         // pending / current match
@@ -168,7 +169,9 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                 else                  { for (int b = 0; b < n; b++) acc |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
                 v0 = (uint32_t)acc; v1 = (uint32_t)(acc >> 32);
             }
-            gcount = (can && mode == kGlobal) ? 0 : gcount;
+            const bool took = can && mode == kGlobal;                // c consumed: e (if there) becomes the next chunk
+            c0 = took ? e0 : c0; c1 = took ? e1 : c1; c2 = took ? e2 : c2; c3 = took ? e3 : c3;
+            gcount = took ? gcount - 1 : gcount;
             APPEND4(v0, v1, v2, v3, n);
             rem -= n;
             mode = rem == 0 ? (int)kIdle : mode;
@@ -349,7 +352,13 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
         if (mode == kGlobal && gcount == 0 && rem > 0) {
             const Vec16 w = load_v16(gptr);
             c0 = w.w[0]; c1 = w.w[1]; c2 = w.w[2]; c3 = w.w[3];
-            gcount = 1; gptr += 16;
+            gcount = 1;
+            if (rem > 16) {                                          // one memory round trip serves two chunks
+                const Vec16 x = load_v16(gptr + 16);
+                e0 = x.w[0]; e1 = x.w[1]; e2 = x.w[2]; e3 = x.w[3];
+                gcount = 2;
+            }
+            gptr += 16 * gcount;
         }
 
         if (final_run && rem == 0 && !done) {
