@@ -174,7 +174,8 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
         // LZ4HIP_HC=wave|lane overrides (A-B runs).
         const char* force = getenv("LZ4HIP_HC");
-        bool lane_per_block = d.n_blocks >= 4096;
+        // (a lane needs ~2.4 s for its block whatever the batch size; the wavefront mapping does ~11 k blocks per second)
+        bool lane_per_block = d.n_blocks >= 32768;
         if (force && force[0] == 'w') lane_per_block = false;
         if (force && force[0] == 'l') lane_per_block = true;
         if (lane_per_block) {
@@ -226,7 +227,10 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     // LZ4HIP_DECODER=wave|lane forces one mapping for every block (profiling / A-B runs).
     const char* force = getenv("LZ4HIP_DECODER");
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
-    if (d.n_blocks < 4096 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
+    // A lone wavefront of the lane mapping needs ~15 ms for its 64 blocks (one ~2 us memory round trip per iteration), so
+    // the mapping only pays once the batch fills the GPU: measured crossover 13 k (D2) .. 28 k (D3) blocks
+    // (profiles/r01/decode_small_batches.txt).
+    if (d.n_blocks < 16384 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
     else if (force && (force[0] == 'l' || force[0] == 's' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
     const bool chunked = force ? (force[0] == 'c' || force[0] == 'w') : true;   // default lane-per-block decoder
     if (lane_filter >= 0 && chunked) {
