@@ -140,12 +140,18 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
         best = t if best is None else min(best, t)
         passes += 1
     assert np.array_equal(back, raw)
+    # LZ4HC on a quarter of the sample (it is ~5x slower per core than the fast encoder)
+    hc_blocks = max(cores, sample_blocks // 4)
+    hc_blocks = min(hc_blocks, sample_blocks)
+    t_hc, hlen = o.batch(codec, "hc", raw[:hc_blocks], lens[:hc_blocks], comp[:hc_blocks], caps[:hc_blocks], threads=cores)
+    assert (hlen > 0).all()
     return {
         "value": round(sample_blocks * 65536 / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
         "sample": f"{sample_blocks} x 64 KiB {DIST_NAMES[dist]} blocks (first blocks of the GPU batch), decode, "
                   f"best of {passes} passes, {cores} threads; encode on the same sample "
                   f"{round(sample_blocks * 65536 / t_enc / 1e9, 3)} GB/s",
         "encode_value": round(sample_blocks * 65536 / t_enc / 1e9, 3),
+        "encode_hc_value": round(hc_blocks * 65536 / t_hc / 1e9, 3), "encode_hc_sample_blocks": hc_blocks,
         "gpu_bytes_equal_cpu_reference": parity,
     }
 
