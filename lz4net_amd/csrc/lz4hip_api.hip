@@ -99,26 +99,53 @@ struct Scratch {
 };
 thread_local Scratch g_scratch;
 
-// HC chain tables: 128 KiB of global scratch per resident workgroup (see lz4hip_hc.hpp)
+// Per-device kernel workspaces (hash tables of the lane encoder, LZ4HC heads/chains): grow-only, shared by every
+// caller of the device.  Kernels that use one must not overlap, whatever streams they were queued on, so a user
+// takes a LEASE: the mutex is held while its work is being queued, its stream first waits for the previous user's
+// completion event, and the release records the new one.  (GPU-side ordering only; the host never blocks on it.)
 struct HcWorkspace {
-    void* p = nullptr; size_t cap = 0; int dev = -1;
+    void* p = nullptr; size_t cap = 0;
+    hipEvent_t last = nullptr; bool busy = false;
     std::mutex mu;
 };
 HcWorkspace g_hc_ws[64], g_fast_ws[64];
 
-int workspace(HcWorkspace* pool, size_t bytes, void** out)
+struct Lease {
+    HcWorkspace* w = nullptr;
+    std::unique_lock<std::mutex> lock;
+    void* p = nullptr;
+};
+
+// Takes the lock on the device's workspace and makes `stream` wait for its previous user.
+int lease_begin(HcWorkspace* pool, hipStream_t stream, Lease& l)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
-    HcWorkspace& w = pool[dev];
-    std::lock_guard<std::mutex> lock(w.mu);
+    l.w = &pool[dev];
+    l.lock = std::unique_lock<std::mutex>(l.w->mu);
+    if (!l.w->last) HIP_TRY(hipEventCreateWithFlags(&l.w->last, hipEventDisableTiming));
+    if (l.w->busy) HIP_TRY(hipStreamWaitEvent(stream, l.w->last, 0));
+    return 0;
+}
+// Makes the leased workspace at least `bytes` large (nonzero return: could not be allocated; the lease stays valid).
+int lease_reserve(Lease& l, size_t bytes)
+{
+    HcWorkspace& w = *l.w;
     if (w.cap < bytes) {
-        if (w.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
-        HIP_TRY(hipMalloc(&w.p, bytes));
+        if (w.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; w.busy = false; }
+        if (hipMalloc(&w.p, bytes) != hipSuccess) { (void)hipGetLastError(); w.p = nullptr; return fail(LZ4HIP_E_MEMORY, "workspace allocation failed"); }
         w.cap = bytes;
     }
-    *out = w.p;
+    l.p = w.p;
+    return 0;
+}
+// Everything queued on `stream` so far is this user's work on the workspace.
+int lease_end(Lease& l, hipStream_t stream)
+{
+    HIP_TRY(hipEventRecord(l.w->last, stream));
+    l.w->busy = true;
+    l.lock.unlock();
     return 0;
 }
 
@@ -145,9 +172,11 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             int64_t groups = (int64_t)cus * wpc;
             if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
             const size_t per_lane = pick == 's' ? (size_t)kSmTableBytes : (size_t)kLaneTableBytes;
-            void* ws = nullptr;
-            int rc = workspace(g_fast_ws, (size_t)groups * 64 * per_lane + 256, &ws);
+            Lease lease;
+            int rc = lease_begin(g_fast_ws, stream, lease);
             if (rc) return rc;
+            if ((rc = lease_reserve(lease, (size_t)groups * 64 * per_lane + 256))) return rc;
+            void* ws = lease.p;
             if (pick == 's') {
                 // epoch-tagged tables: cleared once per launch instead of once per block
                 HIP_TRY(hipMemsetAsync(ws, 0, (size_t)groups * 64 * per_lane + 256, stream));
@@ -160,6 +189,8 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                    (unsigned long long*)ws, (uint8_t*)ws + 256);
             }
+            HIP_TRY(hipGetLastError());
+            if ((rc = lease_end(lease, stream))) return rc;
         } else {
             hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 0);
         }
@@ -178,6 +209,9 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         bool lane_per_block = d.n_blocks >= 32768;
         if (force && force[0] == 'w') lane_per_block = false;
         if (force && force[0] == 'l') lane_per_block = true;
+        Lease lease;
+        int rc = lease_begin(g_hc_ws, stream, lease);
+        if (rc) return rc;
         if (lane_per_block) {
             const size_t slab = small ? kHcLaneSlab16 : kHcLaneSlab32;
             int wpc = kHcLaneWavesPerCu;
@@ -187,28 +221,28 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             for (; wpc >= 1; wpc /= 2) {
                 groups = (int64_t)cus * wpc;
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-                if (workspace(g_hc_ws, (size_t)groups * 64 * slab + 256, &ws) == 0) break;
-                ws = nullptr;
+                if (lease_reserve(lease, (size_t)groups * 64 * slab + 256) == 0) { ws = lease.p; break; }
             }
             if (ws) {
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
                 hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                    (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
                 HIP_TRY(hipGetLastError());
-                return 0;
+                return lease_end(lease, stream);
             }
         }
         const int lds_bytes = small ? kHcLdsHeads16 : kHcLdsHeads32;
         int64_t groups = (int64_t)cus * (small ? kHcGroupsPerCu : 1);
         if (groups > d.n_blocks) groups = d.n_blocks;
-        void* ws = nullptr;
-        int rc = workspace(g_hc_ws, (size_t)groups * kHcGlobalBytesPerGroup + 256, &ws);
-        if (rc) return rc;
+        if ((rc = lease_reserve(lease, (size_t)groups * kHcGlobalBytesPerGroup + 256))) return rc;
+        void* ws = lease.p;
         // first 8 bytes of the workspace: the work counter of the persistent grid
         HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
         if (!small) HIP_TRY(hipFuncSetAttribute((const void*)encode_hc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(encode_hc_kernel, dim3((unsigned)groups), dim3(64), lds_bytes, stream, d,
                            (unsigned long long*)ws, (uint8_t*)ws + 256, lds_bytes);
+        HIP_TRY(hipGetLastError());
+        if ((rc = lease_end(lease, stream))) return rc;
     } else {
         return fail(LZ4HIP_E_ARGUMENT, "mode must be LZ4HIP_MODE_FAST or LZ4HIP_MODE_HC");
     }

@@ -92,3 +92,40 @@ def test_round_robin_sharding_single_process(torch_cuda, oracle):
         assert all(i % world == r and i < n for i in idx)
         parts.append(idx)
     assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_concurrent_streams_share_the_workspace_safely(torch_cuda, oracle):
+    """The lane encoders keep their tables in a per-device workspace; launches from different host threads / streams
+    must not overlap on it (lz4hip_api.hip: workspace leases).  Three threads, each on its own stream, encode
+    different batches that are large enough for the lane mapping; every result must be the oracle's."""
+    import threading
+    torch = torch_cuda
+    from lz4net_amd import batch
+    n, length = 16384, 4096
+    bound = length + length // 255 + 16
+    errors = []
+
+    def worker(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for rep in range(3):
+                    raw = batch.synth(2, 100 + 10 * t + rep, 0, n, length=length)
+                    comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
+                    clen = batch.encode(raw, length, comp, bound)
+                    s.synchronize()
+                    lens = clen.cpu().numpy()
+                    for i in (0, 1, 777, n // 2, n - 1):
+                        want = oracle.compress(oracle.gen(2, 100 + 10 * t + rep, i, 1, length=length)[0])
+                        got = comp[i, :lens[i]].cpu().numpy()
+                        if lens[i] != len(want) or not np.array_equal(got, want):
+                            errors.append((t, rep, i))
+        except Exception as e:                                       # surfaces in the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
