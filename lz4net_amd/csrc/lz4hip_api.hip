@@ -368,7 +368,7 @@ void for_rows(int64_t n, size_t bytes, F f)
 }
 
 // Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
-// The batch is cut into slices of ~64 MiB; per slice: rows are gathered into pinned memory (host threads), ONE
+// The batch is cut into slices (64 MiB .. 1 GiB); per slice: rows are gathered into pinned memory (host threads), ONE
 // host-to-device copy, the kernels, ONE device-to-host copy into pinned memory, rows scattered to the caller.
 // Everything of a slice is queued on the calling thread's stream; the host gathers slice k+1 and scatters
 // slice k-1 while the device is busy with slice k.
@@ -391,7 +391,14 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
         max_dst = dc > max_dst ? dc : max_dst;
     }
     const size_t s_stride = align_up((size_t)max_src + 16, 16), d_stride = align_up((size_t)max_dst + 16, 16);
-    int64_t per_slice = (int64_t)((64u << 20) / (s_stride + d_stride));
+    // slice size: a small batch goes in one piece; a large one in >= 3 slices (so that copies, kernels and the host's
+    // gather/scatter overlap) of 64 MiB .. 1 GiB -- a kernel over fewer than ~1000 blocks costs the same few
+    // milliseconds whatever its size, so slices should not be smaller than they have to be
+    const size_t row_bytes = s_stride + d_stride;
+    int64_t per_slice = (n + 2) / 3;
+    const int64_t lo = (int64_t)((64u << 20) / row_bytes), hi = (int64_t)((1024u << 20) / row_bytes);
+    per_slice = per_slice < lo ? lo : per_slice;
+    per_slice = per_slice > hi ? hi : per_slice;
     per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
     const size_t m = (size_t)per_slice;
     // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
