@@ -24,16 +24,20 @@ constexpr int kLaneTableBytes = 32768;      // per lane: tagged u32[8192] (64k v
 
 // The hash table of one block as this mapping keeps it.  What the algorithm sees is exactly the reference's table
 // (bucket -> last position inserted, empty bucket == position 0, lz4.c:583,642-651); the 64k variant additionally
-// keeps 15 more bits of the inserted sequence's hash product next to the position.  Two sequences with different
-// tags cannot be equal, so most failing probes are decided without touching the input at the candidate position --
-// one scattered memory request less per probe, and scattered requests are what bounds this kernel.
+// keeps, next to the position,
+//   * 10 more bits of the inserted sequence's hash product: two sequences with different tags cannot be equal, so
+//     most failing probes are decided without touching the input at the candidate position -- one far-away DRAM
+//     sector less per probe, and distinct sectors are what bounds this kernel;
+//   * a 6-bit epoch: an entry written for an earlier block of this lane is an empty bucket, so the table is zeroed
+//     once per 63 blocks instead of once per block (32 KiB of stores per 64 KiB block otherwise).
 template <bool GENERIC> struct LaneTable;
 template <> struct LaneTable<true> {        // U32 HashTable[4096], positions as they are
     uint32_t* t; const uint8_t* in;
-    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input)
+    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input, int& epoch)
     {
         t = (uint32_t*)bytes; in = input;
         for (int k = 0; k < kFastTableBytes; k += 16) store_v16(bytes + k, Vec16{ { 0, 0, 0, 0 } });
+        epoch = 63;                                                   // raw positions in the table: the 64k variant must zero it
     }
     LZ4HIP_DEVICE void put(uint32_t word, int pos) { t[FastTable<true>::hash(word)] = (uint32_t)pos; }
     // ref = table[h]; table[h] = pos; returns whether the 4 bytes at ref equal `word` (distance check included)
@@ -46,26 +50,32 @@ template <> struct LaneTable<true> {        // U32 HashTable[4096], positions as
         return load_u32(in + ref) == word;
     }
 };
-template <> struct LaneTable<false> {       // U16 HashTable[8192] as (valid:1 | tag:15 | position:16)
-    uint32_t* t; const uint8_t* in; uint32_t word0;
-    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input)
+template <> struct LaneTable<false> {       // U16 HashTable[8192] as (epoch:6 | tag:10 | position:16)
+    uint32_t* t; const uint8_t* in; uint32_t word0, stamp;
+    // `epoch` is the lane's counter across the blocks it encodes (1..63; 63 also means "contents unknown")
+    LZ4HIP_DEVICE void clear(uint8_t* bytes, const uint8_t* input, int& epoch)
     {
         t = (uint32_t*)bytes; in = input; word0 = load_u32(input);     // an empty bucket is position 0 (never inserted)
-        for (int k = 0; k < kLaneTableBytes; k += 16) store_v16(bytes + k, Vec16{ { 0, 0, 0, 0 } });
+        if (epoch >= 63) {
+            for (int k = 0; k < kLaneTableBytes; k += 16) store_v16(bytes + k, Vec16{ { 0, 0, 0, 0 } });
+            epoch = 0;
+        }
+        epoch++;
+        stamp = (uint32_t)epoch << 26;
     }
     LZ4HIP_DEVICE void put(uint32_t word, int pos)
     {
         const uint32_t prod = word * kGolden;
-        t[prod >> 19] = 0x80000000u | (((prod >> 4) & 0x7FFFu) << 16) | (uint32_t)pos;
+        t[prod >> 19] = stamp | (((prod >> 4) & 0x3FFu) << 16) | (uint32_t)pos;
     }
     LZ4HIP_DEVICE bool exchange(uint32_t word, int pos, int& ref)
     {
-        const uint32_t prod = word * kGolden, h = prod >> 19, tag = (prod >> 4) & 0x7FFFu;
+        const uint32_t prod = word * kGolden, h = prod >> 19, tag = (prod >> 4) & 0x3FFu;
         const uint32_t e = t[h];
-        t[h] = 0x80000000u | (tag << 16) | (uint32_t)pos;
-        ref = (int)(e & 0xFFFFu);                                     // 0 for an empty bucket
-        if ((e >> 31) == 0) return word0 == word;
-        if (((e >> 16) & 0x7FFFu) != tag) return false;               // different sequences for certain
+        t[h] = stamp | (tag << 16) | (uint32_t)pos;
+        if ((e >> 26) != (stamp >> 26)) { ref = 0; return word0 == word; }   // empty bucket (or an older block's entry)
+        ref = (int)(e & 0xFFFFu);
+        if (((e >> 16) & 0x3FFu) != tag) return false;                // different sequences for certain
         return load_u32(in + ref) == word;
     }
 };
@@ -110,14 +120,14 @@ LZ4HIP_DEVICE int lane_put_length(uint8_t* out, int rest)
 }
 
 template <bool GENERIC>
-LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, uint8_t* out, int cap, uint8_t* table_bytes)
+LZ4HIP_DEVICE int lane_encode_fast_block(const uint8_t* __restrict__ in, int n, uint8_t* out, int cap, uint8_t* table_bytes, int& epoch)
 {
     LaneTable<GENERIC> table;
     const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
     int ip = 0, anchor = 0, op = 0;
 
     if (n >= kMinLength) {                                            // lz4.c:615
-        table.clear(table_bytes, in);                                 // fresh table (lz4.c:583); generic: HashTable[hash(0)] = 0 (lz4.c:403) == the fill
+        table.clear(table_bytes, in, epoch);                          // fresh table (lz4.c:583); generic: HashTable[hash(0)] = 0 (lz4.c:403) == the fill
         ip = 1;                                                       // lz4.c:631
         // 8-byte register window over the input for the (mostly sequential) forward reads of the search loop
         uint64_t fw = load_u64(in + ip);                              // n >= 13: in-bounds
@@ -226,14 +236,15 @@ tail:
 __global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables)
 {
     uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLaneTableBytes;
+    int epoch = 63;                                                   // the slab's contents are unknown at launch
     for (;;) {
         const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
         if (blk >= b.n_blocks) return;
         const int n = batch_src_len(b, blk), cap = batch_dst_cap(b, blk);
         const uint8_t* src = batch_src(b, blk);
         uint8_t* dst = batch_dst(b, blk);
-        b.result[blk] = n < k64kLimit ? lane_encode_fast_block<false>(src, n, dst, cap, table)      // lz4.c:783-785
-                                      : lane_encode_fast_block<true>(src, n, dst, cap, table);
+        b.result[blk] = n < k64kLimit ? lane_encode_fast_block<false>(src, n, dst, cap, table, epoch)      // lz4.c:783-785
+                                      : lane_encode_fast_block<true>(src, n, dst, cap, table, epoch);
     }
 }
 

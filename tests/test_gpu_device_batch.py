@@ -129,3 +129,25 @@ def test_concurrent_streams_share_the_workspace_safely(torch_cuda, oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
+    """Lane encoder with one wavefront per CU and 2^20 small blocks: every lane encodes ~64 blocks in a row, so its
+    epoch-stamped table wraps at least once; sampled blocks must be the oracle's bytes and all must round-trip."""
+    torch = torch_cuda
+    from lz4net_amd import batch
+    monkeypatch.setenv("LZ4HIP_ENCODER", "lane")
+    monkeypatch.setenv("LZ4HIP_ENCODER_WAVES_PER_CU", "1")
+    n, length = 1 << 20, 256
+    bound = length + length // 255 + 16
+    raw = batch.synth(2, 31, 0, n, length=length)
+    comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, length, comp, bound)
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, length)
+    assert bool((clen > 0).all()) and bool((used == clen).all())
+    assert batch.count_mismatches(raw, back, length) == 0
+    lens = clen.cpu().numpy()
+    for i in list(range(0, n, 65521)) + [n - 1]:
+        want = oracle.compress(oracle.gen(2, 31, i, 1, length=length)[0])
+        assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i

@@ -174,3 +174,32 @@ def test_encode_hc_limited_output(oracle, lane):
             want = oracle.compress_raw(a, caps[i], hc=True)[0]
             assert res[i] == want, (i, delta, res[i], want)
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
+
+
+def test_encode_lane_many_blocks_per_lane(oracle):
+    """The lane encoder stamps its table entries with a per-lane block counter and zeroes the table only when the
+    counter wraps (63 blocks) or after a block of the generic variant: a lane that encodes many blocks in a row,
+    of both variants, must still produce the reference's bytes for every one of them."""
+    rng = np.random.default_rng(11)
+    sizes = [int(x) for x in rng.integers(13, 3000, 150)] + [65546, 70000, 300, 65547, 64, 5000]
+    blocks = []
+    for i, sz in enumerate(sizes):
+        row = oracle.gen(2 if i % 3 else 3, 77, i, (sz + 65535) // 65536).reshape(-1)[:sz].copy()
+        if i % 7 == 0:
+            row[sz // 2:] = row[:sz - sz // 2]                    # long repeats: bucket reuse inside the block
+        blocks.append(row)
+    res, dst = emu.encode(blocks, lane=True, groups=1)             # 64 lanes, ~2.4 blocks per lane ...
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a)
+        assert res[i] == len(want) and np.array_equal(dst[i, :res[i]], want), (i, a.size)
+    # ... and enough tiny blocks for every lane to wrap its 6-bit counter (64 lanes x > 63 blocks)
+    tiny = []
+    for i in range(64 * 70):
+        sz = 13 + (i * 37) % 180
+        row = oracle.gen(2, 5, i % 50, 1).reshape(-1)[(i % 97) * 7:(i % 97) * 7 + sz].copy()
+        tiny.append(row)
+    res, dst = emu.encode(tiny, lane=True, groups=1)
+    for i in range(0, len(tiny), 13):
+        want = oracle.compress(tiny[i])
+        assert res[i] == len(want) and np.array_equal(dst[i, :res[i]], want), ("tiny", i, tiny[i].size)
+
