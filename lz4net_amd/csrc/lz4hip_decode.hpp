@@ -101,6 +101,14 @@ LZ4HIP_DEVICE void wave_match_copy(uint8_t* dst, int pos, int off, int n)
         wv::mem_sync();
         if (step == dist && dist < 1024) dist += dist;
         cur += step; left -= step;
+        // A power-of-two period has reached exactly 1 KiB: every further KiB is the one just written, lane for lane.
+        // Keep it in registers and only store (a run of zeros or of a short pattern becomes a fill, not a copy).
+        if (dist == 1024 && left >= 1024) {
+            const Vec16 v = load_v16(dst + cur - 1024 + lane * 16);
+            for (; left >= 1024; left -= 1024, cur += 1024)              // (explicit 16-byte global stores: the compiler splits this one into dwords otherwise)
+                wv::store_global16((uint64_t)(dst + cur + lane * 16), v.w[0], v.w[1], v.w[2], v.w[3]);
+            wv::mem_sync();
+        }
     }
 }
 
