@@ -62,8 +62,8 @@ LZ4HIP_DEVICE uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy
 struct alignas(4) Vec16 { uint32_t w[4]; };
 struct alignas(16) Aligned16 { uint32_t w[4]; };                 // 16-byte aligned LDS records
 struct __attribute__((packed)) Packed16 { uint32_t w[4]; };      // 16 bytes at any address
-LZ4HIP_DEVICE Vec16 load_v16(const uint8_t* p) { Vec16 v; __builtin_memcpy(&v, p, 16); return v; }
-LZ4HIP_DEVICE void store_v16(uint8_t* p, const Vec16& v) { __builtin_memcpy(p, &v, 16); }
+LZ4HIP_DEVICE Vec16 load_v16(const uint8_t* p) { Vec16 v; wv::load16(p, v.w[0], v.w[1], v.w[2], v.w[3]); return v; }
+LZ4HIP_DEVICE void store_v16(uint8_t* p, const Vec16& v) { wv::store16(p, v.w[0], v.w[1], v.w[2], v.w[3]); }
 
 // Non-overlapping wave-cooperative copy of n bytes (literal runs: compressed stream <-> raw block).
 // 16 bytes per lane per pass (1 KiB per wave-instruction), byte tail.

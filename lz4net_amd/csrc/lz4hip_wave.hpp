@@ -76,6 +76,19 @@ LZ4HIP_DEVICE void store_global16(uint64_t addr, uint32_t a, uint32_t b, uint32_
     *(__attribute__((address_space(1))) u32x4_unaligned*)addr = v;
 }
 
+// 16 bytes to / from any address, any alignment, as ONE dwordx4 access (a plain 4-byte-aligned struct copy is split
+// into four dword accesses by the compiler).
+LZ4HIP_DEVICE void store16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    u32x4_unaligned v = { a, b, c, d };
+    *(u32x4_unaligned*)p = v;
+}
+LZ4HIP_DEVICE void load16(const void* p, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+{
+    const u32x4_unaligned v = *(const u32x4_unaligned*)p;
+    a = v.x; b = v.y; c = v.z; d = v.w;
+}
+
 LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 LZ4HIP_DEVICE int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
