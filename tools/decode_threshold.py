@@ -1,6 +1,6 @@
 """Decode rate of the wavefront mapping vs the chunked lane mapping for small batches (where is the crossover?)."""
 import os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from lz4net_amd import batch
 for dist in (2, 3):

@@ -1,6 +1,6 @@
 """Device-resident fast-encode rate per distribution (uncompressed GB/s), with a bit-exactness spot check."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from lz4net_amd import batch
 

@@ -1,6 +1,6 @@
 """Is the first large LZ4HC batch slower than the second (workspace allocation inside the timed region)?"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from lz4net_amd import batch
 n = 1 << 18

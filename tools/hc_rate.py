@@ -1,7 +1,7 @@
 """Device-resident LZ4HC encode rate for a few residency settings (uncompressed GB/s), with a round-trip check."""
 import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from lz4net_amd import batch
 
