@@ -151,3 +151,29 @@ def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
     for i in list(range(0, n, 65521)) + [n - 1]:
         want = oracle.compress(oracle.gen(2, 31, i, 1, length=length)[0])
         assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
+
+
+@pytest.mark.parametrize("decoder", ["wave", "chunked"])
+def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder, monkeypatch):
+    """Destination rows at odd addresses and an odd stride, sources at odd addresses too: the 16-byte stores of both
+    decoder mappings (cooperative 64-byte flush of the lane mapping, register fills of the wavefront mapping) must
+    not depend on alignment, and must not touch the bytes between the rows."""
+    torch = torch_cuda
+    from lz4net_amd import batch
+    monkeypatch.setenv("LZ4HIP_DECODER", decoder)
+    n = 2048
+    for dist in (0, 2, 3):
+        raw = batch.synth(dist, 5, 0, n)
+        comp0 = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+        clen = batch.encode(raw, batch.BLOCK, comp0, batch.BOUND)
+        sstride = batch.BOUND_STRIDE + 5
+        sbuf = torch.zeros(n * sstride + 64, dtype=torch.uint8, device="cuda")
+        comp = sbuf[7:7 + n * sstride].view(n, sstride)
+        comp[:, :batch.BOUND_STRIDE] = comp0
+        dstride = batch.BLOCK + 13
+        dbuf = torch.full((n * dstride + 64,), 0xC3, dtype=torch.uint8, device="cuda")
+        back = dbuf[3:3 + n * dstride].view(n, dstride)
+        used = batch.decode(comp, clen, back, batch.BLOCK)
+        assert bool((used == clen).all())
+        assert bool((back[:, :batch.BLOCK] == raw).all()), (decoder, dist)
+        assert bool((back[:, batch.BLOCK:] == 0xC3).all()) and bool((dbuf[:3] == 0xC3).all())
