@@ -57,3 +57,62 @@ def test_product_never_imports_the_oracle():
                                  text, re.M):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lz4hip.h is the boundary a C / cgo / P-Invoke binding generator sees: it must compile as C99 on its
+    own, and a C translation unit must link against the library using nothing but that header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "lz4hip.h"\n'
+        "#include <stdio.h>\n"
+        "int main(void) {\n"
+        "    lz4hip_batch_t b = {0};\n"
+        "    (void)b;\n"
+        '    printf("%s %d %d\\n", lz4hip_codec_name(), lz4hip_compressBound(65536), lz4hip_device_count() >= 0);\n'
+        "    return lz4hip_compressBound(65536) == 65809 ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "abi"
+    lib_dir = os.path.join(root, "lz4net_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-L", lib_dir, "-llz4hip", "-Wl,-rpath," + lib_dir, "-o", str(exe)], check=True, timeout=120)
+    r = subprocess.run([str(exe)], capture_output=True, timeout=60, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "65809" in r.stdout
+
+
+def test_framing_host_logic_properties():
+    """Header walks of the two container formats on synthetic headers (no codec call): varint round trips at the
+    edges of every byte count, chunk lists of LZ4Stream frames, size-prefixed chunks of the legacy frame."""
+    import random
+    from lz4net_amd import stream as st, legacy_frame as lf
+    rnd = random.Random(4)
+    for _ in range(2000):
+        v = rnd.choice([0, 1, 127, 128, 16383, 16384, (1 << 21) - 1, 1 << 21, (1 << 28) - 1, 1 << 28, (1 << 31) - 1]) + rnd.choice([0, 0, 1, -1]) * rnd.randint(0, 3)
+        v = max(v, 0)
+        enc = st.write_varint(v)
+        assert st.read_varint(enc + b"\x00\x00", 0) == (v, len(enc)) and len(enc) == max(1, (v.bit_length() + 6) // 7)
+    for _ in range(200):
+        parts, frame, want = [], b"", []
+        for _ in range(rnd.randint(0, 6)):
+            n = rnd.randint(0, 40)
+            payload = bytes(rnd.randrange(256) for _ in range(n))
+            frame += st.write_varint(0) + st.write_varint(n)
+            want.append((False, n, len(frame), n))
+            frame += payload
+            parts.append(payload)
+        assert st.parse_chunks(frame) == want
+        assert st.decompress_stream(frame) == b"".join(parts)              # raw chunks only: no codec involved
+    for _ in range(200):
+        frame, want = (lf.MAGIC).to_bytes(4, "little"), []
+        for _ in range(rnd.randint(0, 6)):
+            if rnd.random() < 0.2:
+                frame += (lf.MAGIC).to_bytes(4, "little")                   # an appended frame's header
+                continue
+            n = rnd.randint(0, 50)
+            frame += n.to_bytes(4, "little")
+            want.append((len(frame), n))
+            frame += bytes(rnd.randrange(256) for _ in range(n))
+        assert lf.parse_frame(frame) == want
