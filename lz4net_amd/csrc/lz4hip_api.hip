@@ -350,6 +350,27 @@ struct Pinned {
 };
 thread_local Pinned g_pin_in[2], g_pin_out[2];
 
+// Per calling thread: the two copy streams and the events of the three-stage host pipeline (H2D | kernels | D2H).
+struct HostPipe {
+    bool ready = false;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t e_in[2], e_k[2], e_out[2];
+    int init()
+    {
+        if (ready) return 0;
+        HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipEventCreateWithFlags(&e_in[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e_k[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e_out[k], hipEventDisableTiming));
+        }
+        ready = true;
+        return 0;
+    }
+};
+thread_local HostPipe g_pipe;
+
 // f(i) for i in [0, n): on the calling thread for small jobs, on up to 8 threads for large ones (row gathers and
 // scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
 template <class F>
@@ -370,8 +391,9 @@ void for_rows(int64_t n, size_t bytes, F f)
 // Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
 // The batch is cut into slices (64 MiB .. 1 GiB); per slice: rows are gathered into pinned memory (host threads), ONE
 // host-to-device copy, the kernels, ONE device-to-host copy into pinned memory, rows scattered to the caller.
-// Everything of a slice is queued on the calling thread's stream; the host gathers slice k+1 and scatters
-// slice k-1 while the device is busy with slice k.
+// Three streams (copy in | the calling thread's stream for the kernels | copy out) and two sets of buffers: while the
+// kernels of slice k run, slice k+1 is on its way in, slice k-1 on its way out (PCIe is full duplex), and the host
+// gathers / scatters the slices next to those.
 template <class Run>
 int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 {
@@ -404,17 +426,16 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
     const size_t in_lens = align_up(s_stride * m, 256), in_caps = in_lens + align_up(4 * m, 256), in_bytes = in_caps + align_up(4 * m, 256);
     const size_t out_res = align_up(d_stride * m, 256), out_bytes = out_res + align_up(4 * m, 256);
-    if ((rc = g_scratch.reserve(in_bytes + out_bytes))) return rc;
+    if ((rc = g_scratch.reserve(2 * (in_bytes + out_bytes)))) return rc;
     for (int k = 0; k < 2; k++) {
         if ((rc = g_pin_in[k].reserve(in_bytes))) return rc;
         if ((rc = g_pin_out[k].reserve(out_bytes))) return rc;
     }
-    uint8_t* d_in = (uint8_t*)g_scratch.p;
-    uint8_t* d_out = d_in + in_bytes;
-    hipStream_t stream = hipStreamPerThread;
-    hipEvent_t done[2];
-    HIP_TRY(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+    if ((rc = g_pipe.init())) return rc;
+    HostPipe& pp = g_pipe;
+    uint8_t* d_in[2] = { (uint8_t*)g_scratch.p, (uint8_t*)g_scratch.p + in_bytes };
+    uint8_t* d_out[2] = { d_in[1] + in_bytes, d_in[1] + in_bytes + out_bytes };
+    hipStream_t stream = hipStreamPerThread;                         // kernels (and whatever the caller queued before)
 
     auto src_row = [&](int64_t i) { return (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride); };
     auto dst_row = [&](int64_t i) { return (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride); };
@@ -435,14 +456,18 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
             if (nbytes > 0) memcpy(dst_row(first + j), po + d_stride * (size_t)j, (size_t)nbytes);
         });
     };
+#define PIPE_TRY(expr) do { if ((expr) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, #expr " failed"); } } while (0)
 
     int err = 0;
     int64_t prev_first = 0, prev_cnt = 0;
     int slice = 0;
+    // earlier work of this thread on its stream may still use the device buffers of a previous call
+    PIPE_TRY(hipEventRecord(pp.e_k[0], stream));
+    PIPE_TRY(hipEventRecord(pp.e_k[1], stream));
     for (int64_t first = 0; first < n && !err; first += per_slice, slice++) {
         const int64_t cnt = n - first < per_slice ? n - first : per_slice;
         const int slot = slice & 1;
-        // (slot was drained two iterations ago: its scatter ran synchronously below)
+        // (pinned slot: its H2D finished before kernel k-2 did, and its scatter ran synchronously two iterations ago)
         uint8_t* pi = (uint8_t*)g_pin_in[slot].p;
         int32_t* lens = (int32_t*)(pi + in_lens);
         int32_t* caps = (int32_t*)(pi + in_caps);
@@ -451,29 +476,39 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
             const int32_t sl = src_len(first + j);
             if (sl > 0) memcpy(pi + s_stride * (size_t)j, src_row(first + j), (size_t)sl);
         });
-        // the device image of the previous slice is still being read by its D2H copy: same stream, so ordered
-        if (hipMemcpyAsync(d_in, pi, in_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "H2D copy failed"); break; }
+        // copy in: after the kernels that last read this device slot (slice k-2)
+        PIPE_TRY(hipStreamWaitEvent(pp.s_in, pp.e_k[slot], 0));
+        PIPE_TRY(hipMemcpyAsync(d_in[slot], pi, in_bytes, hipMemcpyHostToDevice, pp.s_in));
+        PIPE_TRY(hipEventRecord(pp.e_in[slot], pp.s_in));
+        // kernels: after their input has landed and the copy-out of slice k-2 has left this output slot
+        PIPE_TRY(hipStreamWaitEvent(stream, pp.e_in[slot], 0));
+        if (slice >= 2) PIPE_TRY(hipStreamWaitEvent(stream, pp.e_out[slot], 0));
+        if (err) break;
         lz4hip_batch_t db;
-        db.src = d_in; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(d_in + in_lens);
-        db.dst = d_out; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(d_in + in_caps);
-        db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(d_out + out_res); db.n_blocks = cnt;
+        db.src = d_in[slot]; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(d_in[slot] + in_lens);
+        db.dst = d_out[slot]; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(d_in[slot] + in_caps);
+        db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(d_out[slot] + out_res); db.n_blocks = cnt;
         if ((err = run(&db, stream))) break;
-        if (hipMemcpyAsync(g_pin_out[slot].p, d_out, out_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipEventRecord(done[slot], stream) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "D2H copy failed"); break; }
-        if (prev_cnt) {                                              // drain the previous slice while this one runs
-            if (hipEventSynchronize(done[slot ^ 1]) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, "device fault"); break; }
+        PIPE_TRY(hipEventRecord(pp.e_k[slot], stream));
+        // copy out: after the kernels
+        PIPE_TRY(hipStreamWaitEvent(pp.s_out, pp.e_k[slot], 0));
+        PIPE_TRY(hipMemcpyAsync(g_pin_out[slot].p, d_out[slot], out_bytes, hipMemcpyDeviceToHost, pp.s_out));
+        PIPE_TRY(hipEventRecord(pp.e_out[slot], pp.s_out));
+        if (err) break;
+        if (prev_cnt) {                                              // drain the previous slice while this one is in flight
+            PIPE_TRY(hipEventSynchronize(pp.e_out[slot ^ 1]));
+            if (err) break;
             scatter(prev_first, prev_cnt, slot ^ 1);
         }
         prev_first = first; prev_cnt = cnt;
     }
     if (!err && prev_cnt) {
         const int slot = (slice - 1) & 1;
-        if (hipEventSynchronize(done[slot]) != hipSuccess) err = fail(LZ4HIP_E_DEVICE, "device fault");
-        else scatter(prev_first, prev_cnt, slot);
+        PIPE_TRY(hipEventSynchronize(pp.e_out[slot]));
+        if (!err) scatter(prev_first, prev_cnt, slot);
     }
-    if (err) (void)hipStreamSynchronize(stream);
-    (void)hipEventDestroy(done[0]);
-    (void)hipEventDestroy(done[1]);
+#undef PIPE_TRY
+    if (err) { (void)hipStreamSynchronize(pp.s_in); (void)hipStreamSynchronize(stream); (void)hipStreamSynchronize(pp.s_out); }
     return err;
 }
 
