@@ -291,3 +291,39 @@ def test_host_batch_many_slices_and_layouts(gpu, oracle):
     for i in range(n):
         assert np.array_equal(back[i, :sizes[i]], raw_rows[i, :sizes[i]]), i
         assert (back[i, sizes[i]:] == 0x5A).all(), i
+
+
+def test_host_entry_points_from_several_threads(gpu, oracle):
+    """The host-pointer entry points keep their staging (pinned buffers, copy streams, events) per calling thread and
+    share only the leased device workspaces: four threads encoding and decoding their own batches at the same time
+    must each get the oracle's bytes."""
+    import threading
+    import gpu_helpers as gh
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(100 + t)
+            for rep in range(3):
+                blocks = [oracle.gen(2 + (t + i) % 2, 300 + t, 7 * rep + i, 1)[0][:int(rng.integers(1, 65537))] for i in range(40)]
+                hc = (t + rep) % 2 == 1
+                res, dst = gh.encode(blocks, hc=hc)
+                comps = []
+                for i, a in enumerate(blocks):
+                    want = oracle.compress(a, hc=hc)
+                    if res[i] != len(want) or not np.array_equal(dst[i, :res[i]], want):
+                        errors.append(("enc", t, rep, i))
+                    comps.append(want)
+                used, back = gh.decode(comps, [a.size for a in blocks], known=True)
+                for i, a in enumerate(blocks):
+                    if used[i] != len(comps[i]) or not np.array_equal(back[i, :a.size], a):
+                        errors.append(("dec", t, rep, i))
+        except Exception as e:
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
