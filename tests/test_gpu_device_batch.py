@@ -177,3 +177,26 @@ def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder, monkeypatch):
         assert bool((used == clen).all())
         assert bool((back[:, :batch.BLOCK] == raw).all()), (decoder, dist)
         assert bool((back[:, batch.BLOCK:] == 0xC3).all()) and bool((dbuf[:3] == 0xC3).all())
+
+
+@pytest.mark.parametrize("dist", [2, 3])
+def test_unknown_size_decode_at_scale(torch_cuda, dist):
+    """LZ4_uncompress_unknownOutputSize semantics (Decode(..., knownOutputLength: false), the reference's default)
+    through the lane mapping on a batch large enough to select it: the result is the number of bytes produced."""
+    torch = torch_cuda
+    from lz4net_amd import batch
+    n = 1 << 16
+    raw = batch.synth(dist, 77, 0, n)
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    stride = batch.BLOCK + 64
+    back = torch.full((n, stride), 0x3C, dtype=torch.uint8, device="cuda")
+    produced = batch.decode(comp, clen, back, batch.BLOCK + 40, known_output_size=False)
+    assert bool((produced == batch.BLOCK).all())
+    assert bool((back[:, :batch.BLOCK] == raw).all())
+    assert bool((back[:, batch.BLOCK:] == 0x3C).all())
+    # a capacity that is too small is an error at some position of the source: negative result, nothing past the capacity
+    back.fill_(0x3C)
+    short = batch.decode(comp, clen, back, batch.BLOCK - 1, known_output_size=False)
+    assert bool((short < 0).all())
+    assert bool((back[:, batch.BLOCK - 1:] == 0x3C).all())
