@@ -327,3 +327,27 @@ def test_host_entry_points_from_several_threads(gpu, oracle):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def test_chunked_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatch):
+    """GPU twin of the emulator test of the same name: 256 identical crafted blocks through the lane mapping (every
+    lane flushes in the same iteration; matches of every length 4..40 at offsets inside / just behind / far behind
+    the LDS ring, periodic matches, literal runs of 0..80 bytes), known and unknown output size."""
+    monkeypatch.setenv("LZ4HIP_DECODER", "chunked")
+    rng = np.random.default_rng(23)
+    data = bytearray(rng.integers(0, 256, 7000, dtype=np.uint8).tobytes())
+    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 500, 4097, 6000):
+        for ml in list(range(4, 41)) + [64, 65, 100]:
+            lit = int(rng.integers(0, 81)) if (off + ml) % 5 == 0 else int(rng.integers(0, 4))
+            data += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+            start = len(data) - off
+            for i in range(ml):
+                data.append(data[start + i])
+            data.append(int(rng.integers(0, 256)))
+    block = np.frombuffer(bytes(data), dtype=np.uint8)
+    comp = oracle.compress(block)
+    n = 256
+    used, back = gpu.decode([comp] * n, [block.size] * n, known=True)
+    assert (used == len(comp)).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
+    produced, back = gpu.decode([comp] * n, [block.size + 9] * n, known=False)
+    assert (produced == block.size).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))

@@ -203,3 +203,29 @@ def test_encode_lane_many_blocks_per_lane(oracle):
         want = oracle.compress(tiny[i])
         assert res[i] == len(want) and np.array_equal(dst[i, :res[i]], want), ("tiny", i, tiny[i].size)
 
+
+
+def test_chunked_decoder_lockstep_lanes_and_copy_lengths(oracle):
+    """64 identical blocks keep the 64 lanes of the lane-mapped decoder in lockstep, so every lane wants to flush in
+    the same iteration (four rounds of the cooperative flush) -- on blocks built to contain matches of every length
+    4..40 at offsets inside the ring, just behind it and far behind it (16- and 32-byte fetches), periodic matches and
+    literal runs of 0..80 bytes."""
+    rng = np.random.default_rng(23)
+    data = bytearray(rng.integers(0, 256, 7000, dtype=np.uint8).tobytes())
+    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 500, 4097, 6000):
+        for ml in list(range(4, 41)) + [64, 65, 100]:
+            lit = int(rng.integers(0, 81)) if (off + ml) % 5 == 0 else int(rng.integers(0, 4))
+            data += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+            start = len(data) - off
+            for i in range(ml):                                   # byte-wise LZ77 copy (overlap allowed)
+                data.append(data[start + i])
+            data.append(int(rng.integers(0, 256)))                # break the match
+    block = np.frombuffer(bytes(data), dtype=np.uint8)
+    assert 30000 < block.size < 200000
+    comp = oracle.compress(block)
+    for known in (True, False):
+        comps = [np.concatenate([comp, np.zeros(1024, np.uint8)]) for _ in range(64)]
+        res, dst = emu.decode(comps, [block.size] * 64, known=known, src_lens=None if known else [len(comp)] * 64, chunked=128)
+        for i in range(64):
+            assert res[i] == (len(comp) if known else block.size), (known, i, res[i])
+            assert np.array_equal(dst[i, :block.size], block), (known, i)
