@@ -1,8 +1,8 @@
 // lz4hip_decode_chunked.hpp -- lane-per-block LZ4 decoder as a CONVERGENT state machine:
 // every loop iteration every lane (b) produces at most 16 output bytes from whatever source its state
 // says, (a) parses a sequence header if its copy is finished -- appending the sequence's literals right
-// away when they sit in the header window --, (c) flushes 64 bytes of finished output, (d) requests the
-// next 16 source bytes if it is copying from global memory.
+// away when they sit in the header window --, (c) takes part in the cooperative flush of finished 64-byte
+// lines, (d) requests the next 16 (or 32) source bytes if it is copying from global memory.
 // Same functions / return conventions as lz4hip_decode.hpp (LZ4_uncompress, original/lz4.c:812-914;
 // LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
 //
@@ -18,12 +18,13 @@
 //   * per-lane output ring in LDS (dword-interleaved across lanes: conflict free); appends and ring reads
 //     are byte-granular through v_perm_b32 on aligned dwords (no 64-bit shifts, no masking: bytes written
 //     past the end of an append are overwritten by the next one); matches whose offset fits the ring are
-//     served from LDS; finished output leaves 64 bytes at a time as four back-to-back 16-byte stores;
+//     served from LDS; finished output leaves 64 bytes at a time, four lanes storing one lane's line, so that a
+//     store instruction covers 16 full lines instead of touching 64 (stage (c));
 //   * every header byte (token, one literal-length byte, <= 11 literals, offset, one match-length byte)
 //     comes out of a 32-byte register window over the compressed stream that slides 16 bytes at a time;
 //     its loads are requested at least one header before they are needed;
-//   * far matches and long literal runs stream through a 16-byte register pair that is requested at
-//     the END of an iteration and consumed in the next ones;
+//   * far matches and long literal runs stream through 16 (32 when more than 16 bytes are left) bytes of
+//     registers that are requested at the END of an iteration and consumed in the next ones;
 //   * the hot paths are straight-line code on integer state (selects, unconditional LDS accesses whose
 //     result is discarded when not needed); only rare events are branches: length runs of 0xFF bytes,
 //     the last bytes of the input, offset 0, errors, the final literal run.
