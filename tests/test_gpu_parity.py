@@ -351,3 +351,30 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatc
     assert (used == len(comp)).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
     produced, back = gpu.decode([comp] * n, [block.size + 9] * n, known=False)
     assert (produced == block.size).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
+
+
+def test_decode_arbitrary_streams(gpu, oracle, decoder):
+    """GPU twin of the emulator test: streams no encoder of ours produced (tests/stream_fuzz.py), well formed or
+    not -- same bytes and same return codes as the oracle for both decoders, every mapping, nothing written past the
+    capacity."""
+    import stream_fuzz
+    cs = stream_fuzz.cases(99, 600)
+    comps = [c for (c, _), _ in cs]
+    sizes = [t for _, t in cs]
+    pad = [np.concatenate([c, np.zeros(t + 1024, np.uint8)]) for c, t in zip(comps, sizes)]
+    res, dst = gpu.decode(pad, sizes, known=True)
+    for i, (c, t) in enumerate(zip(comps, sizes)):
+        w, out = oracle.uncompress_raw(c, t)
+        assert res[i] == w, ("known", i, res[i], w)
+        if w >= 0:
+            assert np.array_equal(dst[i, :t], out[:t]), ("known", i)
+        assert (dst[i, t:] == 0xA5).all(), ("known canary", i)
+    caps = [t + (i % 3) * 7 - (5 if i % 11 == 0 else 0) for i, t in enumerate(sizes)]
+    padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c in comps]
+    res, dst = gpu.decode(padu, caps, known=False, src_lens=[len(c) for c in comps])
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        w, out = oracle.uncompress_unknown_raw(c, len(c), cap)
+        assert res[i] == w, ("unknown", i, res[i], w)
+        if w >= 0:
+            assert np.array_equal(dst[i, :w], out[:w]), ("unknown", i)
+        assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)

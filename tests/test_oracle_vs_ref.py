@@ -85,3 +85,25 @@ def test_alignment_independence(oracle, reference):
         out = np.zeros(compress_bound(65536), dtype=np.uint8)
         ret = reference._hc(big.ctypes.data + off, out.ctypes.data, 65536, out.size)
         assert ret == len(want) and np.array_equal(out[:ret], want), off
+
+
+def test_decoders_identical_on_arbitrary_streams(oracle, reference):
+    """Streams no encoder produced (tests/stream_fuzz.py: odd but legal sequences, truncated / extended / corrupted /
+    zero-offset streams): the restatement and the reference's own C return the same code and the same bytes."""
+    import stream_fuzz
+    for seed in (2026, 7):
+        cs = stream_fuzz.cases(seed, 400)
+        for i, ((c, raw), t) in enumerate(cs):
+            d1, o1 = reference.uncompress_raw(c, t)
+            d2, o2 = oracle.uncompress_raw(c, t)
+            assert d1 == d2, ("known", seed, i, d1, d2)
+            if d1 >= 0:
+                assert np.array_equal(o1[:t], o2[:t]), ("known bytes", seed, i)
+            if raw is not None:
+                assert d1 == len(c) and np.array_equal(o1[:t], raw), ("well formed", seed, i)
+            for cap in (t, t + 3, t - 1):
+                u1, p1 = reference.uncompress_unknown_raw(c, len(c), cap)
+                u2, p2 = oracle.uncompress_unknown_raw(c, len(c), cap)
+                assert u1 == u2, ("unknown", seed, i, cap, u1, u2)
+                if u1 >= 0:
+                    assert np.array_equal(p1[:u1], p2[:u1]), ("unknown bytes", seed, i, cap)

@@ -229,3 +229,36 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(oracle):
         for i in range(64):
             assert res[i] == (len(comp) if known else block.size), (known, i, res[i])
             assert np.array_equal(dst[i, :block.size], block), (known, i)
+
+
+@pytest.mark.parametrize("lane", [False, True, "chunked128"], ids=["wave-per-block", "lane-per-block", "chunked128"])
+def test_decode_arbitrary_streams(oracle, lane):
+    """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
+    them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching
+    a byte past the capacity."""
+    import stream_fuzz
+    cs = stream_fuzz.cases(2026, 240)
+    comps = [c for (c, _), _ in cs]
+    sizes = [t for _, t in cs]
+    for (c, raw), t in cs:
+        if raw is not None:
+            assert raw.size == t
+            ret, out = oracle.uncompress_raw(c, t)
+            assert ret == len(c) and np.array_equal(out[:t], raw)          # the generator and the oracle agree on well-formed streams
+    want_k = [oracle.uncompress_raw(c, t) for c, t in zip(comps, sizes)]
+    pad = [np.concatenate([c, np.zeros(t + 1024, np.uint8)]) for c, t in zip(comps, sizes)]
+    res, dst = emu.decode(pad, sizes, known=True, **_mapping(lane))
+    for i, (w, out) in enumerate(want_k):
+        assert res[i] == w, ("known", i, res[i], w)
+        if w >= 0:
+            assert np.array_equal(dst[i, :sizes[i]], out[:sizes[i]]), ("known", i)
+        assert (dst[i, sizes[i]:] == 0xA5).all(), ("known canary", i)
+    caps = [t + (i % 3) * 7 - (5 if i % 11 == 0 else 0) for i, t in enumerate(sizes)]
+    want_u = [oracle.uncompress_unknown_raw(c, len(c), cap) for c, cap in zip(comps, caps)]
+    padu = [np.concatenate([c, np.zeros(8, np.uint8)]) for c in comps]
+    res, dst = emu.decode(padu, caps, known=False, src_lens=[len(c) for c in comps], **_mapping(lane))
+    for i, (w, out) in enumerate(want_u):
+        assert res[i] == w, ("unknown", i, res[i], w)
+        if w >= 0:
+            assert np.array_equal(dst[i, :w], out[:w]), ("unknown", i)
+        assert (dst[i, max(caps[i], 0):] == 0xA5).all(), ("unknown canary", i)
