@@ -205,8 +205,9 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
         // LZ4HIP_HC=wave|lane overrides (A-B runs).
         const char* force = getenv("LZ4HIP_HC");
-        // (a lane needs ~2.4 s for its block whatever the batch size; the wavefront mapping does ~11 k blocks per second)
-        bool lane_per_block = d.n_blocks >= 32768;
+        // (a lane needs 1.3 - 2.4 s for its block, growing with the number of lanes in flight; the wavefront mapping does
+        //  ~11 k blocks per second: measured crossover at 16 k blocks, profiles/r01/hc_small_batches.txt)
+        bool lane_per_block = d.n_blocks >= 16384;
         if (force && force[0] == 'w') lane_per_block = false;
         if (force && force[0] == 'l') lane_per_block = true;
         Lease lease;
