@@ -41,9 +41,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--hc-blocks", type=int, default=1 << 18, help="blocks for the LZ4HC extra (SURVEY 8d C4: 2^18; 0 = skip)")
-    ap.add_argument("--decoder", choices=["auto", "lane", "wave", "staged", "chunked"], default="auto",
+    ap.add_argument("--decoder", choices=["auto", "lane", "wave"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
-    ap.add_argument("--encoder", choices=["auto", "lane", "wave", "sm"], default="auto")
+    ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     return ap.parse_args()
 

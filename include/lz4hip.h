@@ -35,6 +35,9 @@ extern "C" {
 #define LZ4HIP_MODE_HC   1
 
 /* ---- information ------------------------------------------------------------------------------ */
+/* lz4hip_uncompress is not told its source length (neither is LZ4_uncompress, original/lz4.c:812-814): like the
+ * reference it trusts the stream and reads on until `osize` bytes are produced -- on a corrupt stream that walk is
+ * unbounded on the host side exactly as the reference's is.  Use lz4hip_uncompress_bounded for untrusted input. */
 /* Counterpart of LZ4Codec.CodecName (src/LZ4/LZ4Codec.cs:298-308), e.g. "HIP gfx950 (AMD Instinct MI355X)". */
 const char* lz4hip_codec_name(void);
 int         lz4hip_device_count(void);
@@ -85,6 +88,23 @@ int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, v
 /* Host-resident batches: stages through device memory (H2D, kernels, D2H) and synchronises. */
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode);
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------
+ * Launch counters per kernel family since the library was loaded: which block->hardware mapping a call
+ * actually used (the GPU tests assert these).  Copies min(n, LZ4HIP_K_COUNT) counters, returns LZ4HIP_K_COUNT. */
+#define LZ4HIP_K_DECODE_WAVE 0   /* lz4hip_decode.hpp:         one wavefront per block */
+#define LZ4HIP_K_DECODE_LANE 1   /* lz4hip_decode_chunked.hpp: one lane per block      */
+#define LZ4HIP_K_ENCODE_WAVE 2
+#define LZ4HIP_K_ENCODE_LANE 3
+#define LZ4HIP_K_HC_WAVE     4
+#define LZ4HIP_K_HC_LANE     5
+#define LZ4HIP_K_COUNT       6
+int lz4hip_dispatch_counts(uint64_t* counts, int n);
+
+/* Frees the grow-only kernel workspaces (encoder hash-table / LZ4HC slabs) of the CURRENT device after
+ * waiting for their last user.  The reference frees its tables before every return (original/lz4.c:780-786);
+ * the library caches them between calls, this is how a caller gets the memory back. */
+int lz4hip_release_workspaces(void);
 
 /* ---- device-side synthetic data + verification (bench / tests) ---------------------
  * dist: 0 zeros, 1 incompressible, 2 reference fuzzer generator (original/fuzzer.c:149-168), 3 record-like.

@@ -32,6 +32,8 @@ SYMBOLS = [
     ("lz4hip_device_count", C.c_int, []),
     ("lz4hip_last_error", C.c_char_p, []),
     ("lz4hip_compressBound", C.c_int, [C.c_int]),
+    ("lz4hip_dispatch_counts", C.c_int, [C.c_void_p, C.c_int]),
+    ("lz4hip_release_workspaces", C.c_int, []),
     ("lz4hip_compress_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("lz4hip_compress", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("lz4hip_compressHC_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -69,6 +71,17 @@ def lib():
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+K_DECODE_WAVE, K_DECODE_LANE, K_ENCODE_WAVE, K_ENCODE_LANE, K_HC_WAVE, K_HC_LANE, K_COUNT = range(7)
+
+
+def dispatch_counts() -> list:
+    """Launches per kernel family since the library was loaded (lz4hip_dispatch_counts)."""
+    buf = (C.c_uint64 * K_COUNT)()
+    n = lib().lz4hip_dispatch_counts(buf, K_COUNT)
+    assert n == K_COUNT
+    return list(buf)
 
 
 def check(rc: int) -> int:

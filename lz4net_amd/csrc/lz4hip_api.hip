@@ -6,18 +6,16 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
-#include "lz4hip_decode_lane.hpp"
-#include "lz4hip_decode_staged.hpp"
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
-#include "lz4hip_encode_sm.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <cstring>
@@ -30,6 +28,15 @@ using namespace lz4hip;
 namespace {
 
 thread_local std::string g_last_error;
+
+// Launch counters per kernel family (lz4hip_dispatch_counts): what the tests assert so that a test that names a
+// mapping is known to have run it.
+std::atomic<uint64_t> g_dispatch[LZ4HIP_K_COUNT];
+void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxed); }
+
+// A lone wavefront of the lane mapping needs milliseconds for its 64 blocks, so the mapping only pays once the
+// batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
+constexpr int64_t kLaneDecodeMinBlocks = 16384;
 
 int fail(int code, const std::string& what)
 {
@@ -97,7 +104,6 @@ struct Scratch {
     }
     ~Scratch() { /* the HIP runtime may already be gone at thread exit: leak on purpose */ }
 };
-thread_local Scratch g_scratch;
 
 // Per-device kernel workspaces (hash tables of the lane encoder, LZ4HC heads/chains): grow-only, shared by every
 // caller of the device.  Kernels that use one must not overlap, whatever streams they were queued on, so a user
@@ -158,41 +164,42 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // one lane per block, tables in a global slab).  Batches large enough to fill the lanes use the
         // latter.  LZ4HIP_ENCODER=wave|lane overrides (A-B runs).
         const char* force = getenv("LZ4HIP_ENCODER");
-        // 'l' (default for large batches): lane-per-block direct; 's': lane-per-block state machine; 'w': wavefront.
-        // Both lane mappings end up bound by the distinct DRAM sectors their per-lane hash tables touch (~3 MB per
-        // 64 KiB block); the direct one, with tagged + epoch-stamped tables, is the faster of the two (45 vs 33 GB/s).
+        // 'l' (default for large batches): one lane per block; 'w': one wavefront per block.
         char pick = d.n_blocks >= 16384 ? 'l' : 'w';
-        if (force && (force[0] == 'w' || force[0] == 'l' || force[0] == 's')) pick = force[0];
+        if (force && (force[0] == 'w' || force[0] == 'l')) pick = force[0];
         if (pick != 'w') {
             int dev = 0, cus = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            int wpc = pick == 's' ? kSmEncodeWavesPerCu : kLaneEncodeWavesPerCu;
+            int wpc = kLaneEncodeWavesPerCu;
             if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
-            int64_t groups = (int64_t)cus * wpc;
-            if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-            const size_t per_lane = pick == 's' ? (size_t)kSmTableBytes : (size_t)kLaneTableBytes;
             Lease lease;
             int rc = lease_begin(g_fast_ws, stream, lease);
             if (rc) return rc;
-            if ((rc = lease_reserve(lease, (size_t)groups * 64 * per_lane + 256))) return rc;
-            void* ws = lease.p;
-            if (pick == 's') {
-                // epoch-tagged tables: cleared once per launch instead of once per block
-                HIP_TRY(hipMemsetAsync(ws, 0, (size_t)groups * 64 * per_lane + 256, stream));
-                hipLaunchKernelGGL(encode_fast_sm_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                                   (unsigned long long*)ws, (uint8_t*)ws + 256);
-                // blocks of LZ4_64KLIMIT bytes and more use the u32-table variant: wavefront kernel, filtered
-                hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 1);
-            } else {
+            // the slab holds one table per resident lane; if it cannot be had, halve the residency, and
+            // in the end fall back to the wavefront mapping (which needs no workspace)
+            void* ws = nullptr;
+            int64_t groups = 0;
+            for (; wpc >= 1; wpc /= 2) {
+                groups = (int64_t)cus * wpc;
+                if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
+                if (lease_reserve(lease, (size_t)groups * 64 * (size_t)kLaneTableBytes + 256) == 0) { ws = lease.p; break; }
+            }
+            if (ws) {
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
                 hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                    (unsigned long long*)ws, (uint8_t*)ws + 256);
+                HIP_TRY(hipGetLastError());
+                count_dispatch(LZ4HIP_K_ENCODE_LANE);
+                if ((rc = lease_end(lease, stream))) return rc;
+            } else {
+                lease.lock.unlock();
+                pick = 'w';
             }
-            HIP_TRY(hipGetLastError());
-            if ((rc = lease_end(lease, stream))) return rc;
-        } else {
+        }
+        if (pick == 'w') {
             hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 0);
+            count_dispatch(LZ4HIP_K_ENCODE_WAVE);
         }
     } else if (mode == LZ4HIP_MODE_HC) {
         int dev = 0, cus = 0;
@@ -229,6 +236,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                    (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
                 HIP_TRY(hipGetLastError());
+                count_dispatch(LZ4HIP_K_HC_LANE);
                 return lease_end(lease, stream);
             }
         }
@@ -243,6 +251,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         hipLaunchKernelGGL(encode_hc_kernel, dim3((unsigned)groups), dim3(64), lds_bytes, stream, d,
                            (unsigned long long*)ws, (uint8_t*)ws + 256, lds_bytes);
         HIP_TRY(hipGetLastError());
+        count_dispatch(LZ4HIP_K_HC_WAVE);
         if ((rc = lease_end(lease, stream))) return rc;
     } else {
         return fail(LZ4HIP_E_ARGUMENT, "mode must be LZ4HIP_MODE_FAST or LZ4HIP_MODE_HC");
@@ -256,77 +265,34 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
     // Two mappings of the same decoder (lz4hip_decode.hpp: one wavefront per block, coalesced wide copies;
-    // lz4hip_decode_lane.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
+    // lz4hip_decode_chunked.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
     // partitioned per block by block_selected(): two launches, each skipping the other's blocks.
     // Small batches cannot fill the lanes and use the wavefront mapping only.
-    // LZ4HIP_DECODER=wave|lane forces one mapping for every block (profiling / A-B runs).
+    // LZ4HIP_DECODER=wave|lane forces one mapping for EVERY block, whatever the batch size (tests, A-B runs).
     const char* force = getenv("LZ4HIP_DECODER");
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
-    // A lone wavefront of the lane mapping needs ~15 ms for its 64 blocks (one ~2 us memory round trip per iteration), so
-    // the mapping only pays once the batch fills the GPU: measured crossover 13 k (D2) .. 28 k (D3) blocks
-    // (profiles/r01/decode_small_batches.txt).
-    if (d.n_blocks < 16384 || (force && force[0] == 'w')) { wave_filter = kAllBlocks; lane_filter = -1; }
-    else if (force && (force[0] == 'l' || force[0] == 's' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
-    const bool chunked = force ? (force[0] == 'c' || force[0] == 'w') : true;   // default lane-per-block decoder
-    if (lane_filter >= 0 && chunked) {
-        // lane-per-block convergent state machine with a per-lane LDS output ring (lz4hip_decode_chunked.hpp)
+    if (force && force[0] == 'w') { wave_filter = kAllBlocks; lane_filter = -1; }
+    else if (force && (force[0] == 'l' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
+    else if (d.n_blocks < kLaneDecodeMinBlocks) { wave_filter = kAllBlocks; lane_filter = -1; }
+    if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
         int ring = kChunkedRingBytes;
-        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
-        const unsigned lds = 0;   // the kernel's LDS is static
+        if (const char* e = getenv("LZ4HIP_RING_BYTES")) ring = atoi(e);
 #define LZ4HIP_LAUNCH_CHUNKED(R)                                                                                      \
         do {                                                                                                          \
-            if (known) hipLaunchKernelGGL((decode_chunked_kernel<true, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);   \
-            else       hipLaunchKernelGGL((decode_chunked_kernel<false, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);  \
+            if (known) hipLaunchKernelGGL((decode_chunked_kernel<true, R>), dim3(grid), dim3(64), 0, stream, d, lane_filter);   \
+            else       hipLaunchKernelGGL((decode_chunked_kernel<false, R>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
         } while (0)
-        if (ring == 128) LZ4HIP_LAUNCH_CHUNKED(128);
-        else if (ring == 512) LZ4HIP_LAUNCH_CHUNKED(512);
-        else if (ring == 1024) LZ4HIP_LAUNCH_CHUNKED(1024);
-        else LZ4HIP_LAUNCH_CHUNKED(256);
+        if (ring == 256) LZ4HIP_LAUNCH_CHUNKED(256);
+        else LZ4HIP_LAUNCH_CHUNKED(128);
 #undef LZ4HIP_LAUNCH_CHUNKED
-        lane_filter = -1;
-    }
-    bool staged = kStagedByDefault;
-    if (force && force[0] == 's') staged = true;
-    if (force && force[0] == 'l') staged = false;
-    if (lane_filter >= 0 && staged) {
-        // lane-per-block with a per-lane output ring in LDS (lz4hip_decode_staged.hpp)
-        const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        int ring = kStagedRingBytes;
-        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) ring = atoi(e);
-        const unsigned lds = 64u * (unsigned)ring;
-#define LZ4HIP_LAUNCH_STAGED(R)                                                                                      \
-        do {                                                                                                          \
-            if (lds > 65536u) {                                                                                       \
-                HIP_TRY(hipFuncSetAttribute((const void*)decode_staged_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-                HIP_TRY(hipFuncSetAttribute((const void*)decode_staged_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            }                                                                                                         \
-            if (known) hipLaunchKernelGGL((decode_staged_kernel<true, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);   \
-            else       hipLaunchKernelGGL((decode_staged_kernel<false, R>), dim3(grid), dim3(64), lds, stream, d, lane_filter);  \
-        } while (0)
-        if (ring == 256) LZ4HIP_LAUNCH_STAGED(256);
-        else if (ring == 1024) LZ4HIP_LAUNCH_STAGED(1024);
-        else if (ring == 2048) LZ4HIP_LAUNCH_STAGED(2048);
-        else LZ4HIP_LAUNCH_STAGED(512);
-#undef LZ4HIP_LAUNCH_STAGED
-    } else if (lane_filter >= 0) {
-        const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        // Residency throttle: the kernel uses no LDS; reserving some caps the wavefronts per CU so that the
-        // cache lines the resident lanes are streaming through (one input, one output, match sources per
-        // lane) stay in the XCD's L2.  LZ4HIP_LANE_LDS_KB overrides (tuning runs).
-        unsigned lds = kLaneDecodeLdsBytes;
-        if (const char* e = getenv("LZ4HIP_LANE_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
-        if (lds > 65536u) {
-            HIP_TRY(hipFuncSetAttribute((const void*)decode_lane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)decode_lane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (known) hipLaunchKernelGGL(decode_lane_kernel<true>, dim3(grid), dim3(64), lds, stream, d, lane_filter);
-        else       hipLaunchKernelGGL(decode_lane_kernel<false>, dim3(grid), dim3(64), lds, stream, d, lane_filter);
+        count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {
         const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
         if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
         else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
+        count_dispatch(LZ4HIP_K_DECODE_WAVE);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -349,16 +315,17 @@ struct Pinned {
     }
     ~Pinned() { /* see ~Scratch */ }
 };
-thread_local Pinned g_pin_in[2], g_pin_out[2];
 
 // Per calling thread: the two copy streams and the events of the three-stage host pipeline (H2D | kernels | D2H).
 struct HostPipe {
     bool ready = false;
+    int dev = -1;                // streams and events belong to a device: one set per (thread, device)
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t e_in[2], e_k[2], e_out[2];
     int init()
     {
         if (ready) return 0;
+        HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
@@ -370,7 +337,21 @@ struct HostPipe {
         return 0;
     }
 };
-thread_local HostPipe g_pipe;
+// Everything a calling thread needs to stage host batches through ONE device: scratch, pinned slots, pipeline.
+// Indexed by the device that is current when the call is made, so a thread may hipSetDevice() between calls
+// (and the multi-device entry points run one worker thread per device).
+struct HostContext {
+    Scratch scratch;
+    Pinned pin_in[2], pin_out[2];
+    HostPipe pipe;
+};
+HostContext* host_context(int dev)
+{
+    static thread_local HostContext* ctx[64] = {};
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!ctx[dev]) ctx[dev] = new HostContext();   // lives as long as the thread (see ~Scratch)
+    return ctx[dev];
+}
 
 // f(i) for i in [0, n): on the calling thread for small jobs, on up to 8 threads for large ones (row gathers and
 // scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
@@ -427,13 +408,20 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
     const size_t in_lens = align_up(s_stride * m, 256), in_caps = in_lens + align_up(4 * m, 256), in_bytes = in_caps + align_up(4 * m, 256);
     const size_t out_res = align_up(d_stride * m, 256), out_bytes = out_res + align_up(4 * m, 256);
+    int dev_now = 0;
+    HIP_TRY(hipGetDevice(&dev_now));
+    HostContext* hc = host_context(dev_now);
+    if (!hc) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+    Scratch& g_scratch = hc->scratch;
+    Pinned* g_pin_in = hc->pin_in;
+    Pinned* g_pin_out = hc->pin_out;
     if ((rc = g_scratch.reserve(2 * (in_bytes + out_bytes)))) return rc;
     for (int k = 0; k < 2; k++) {
         if ((rc = g_pin_in[k].reserve(in_bytes))) return rc;
         if ((rc = g_pin_out[k].reserve(out_bytes))) return rc;
     }
-    if ((rc = g_pipe.init())) return rc;
-    HostPipe& pp = g_pipe;
+    if ((rc = hc->pipe.init())) return rc;
+    HostPipe& pp = hc->pipe;
     uint8_t* d_in[2] = { (uint8_t*)g_scratch.p, (uint8_t*)g_scratch.p + in_bytes };
     uint8_t* d_out[2] = { d_in[1] + in_bytes, d_in[1] + in_bytes + out_bytes };
     hipStream_t stream = hipStreamPerThread;                         // kernels (and whatever the caller queued before)
@@ -488,7 +476,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
         lz4hip_batch_t db;
         db.src = d_in[slot]; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(d_in[slot] + in_lens);
         db.dst = d_out[slot]; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(d_in[slot] + in_caps);
-        db.dst_cap_all = 0; db.src_len_all = 0; db.result = (int32_t*)(d_out[slot] + out_res); db.n_blocks = cnt;
+        db.dst_cap_all = 0; db.src_len_all = (int32_t)max_src;   /* upper-bound hint */ db.result = (int32_t*)(d_out[slot] + out_res); db.n_blocks = cnt;
         if ((err = run(&db, stream))) break;
         PIPE_TRY(hipEventRecord(pp.e_k[slot], stream));
         // copy out: after the kernels
@@ -574,6 +562,28 @@ const char* lz4hip_codec_name(void)
 }
 
 int lz4hip_compressBound(int isize) { return isize + isize / 255 + 16; }
+
+int lz4hip_dispatch_counts(uint64_t* counts, int n)
+{
+    for (int k = 0; counts && k < n && k < LZ4HIP_K_COUNT; k++) counts[k] = g_dispatch[k].load(std::memory_order_relaxed);
+    return LZ4HIP_K_COUNT;
+}
+
+int lz4hip_release_workspaces(void)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+    for (HcWorkspace* pool : { g_hc_ws, g_fast_ws }) {
+        HcWorkspace& w = pool[dev];
+        std::unique_lock<std::mutex> lock(w.mu);
+        if (!w.p) continue;
+        if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
+        HIP_TRY(hipFree(w.p));
+        w.p = nullptr; w.cap = 0; w.busy = false;
+    }
+    return 0;
+}
 
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream)
 {

@@ -59,6 +59,8 @@ LZ4HIP_DEVICE bool block_selected(int filter, int src_len, int out_size)
 // Unaligned little-endian loads/stores (gfx950 runs with unaligned access enabled; hipcc lowers
 // these to single global_load/store_dword[xN] instructions).
 LZ4HIP_DEVICE uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+LZ4HIP_DEVICE uint64_t load_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+LZ4HIP_DEVICE void store_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 struct alignas(4) Vec16 { uint32_t w[4]; };
 struct alignas(16) Aligned16 { uint32_t w[4]; };                 // 16-byte aligned LDS records
 struct __attribute__((packed)) Packed16 { uint32_t w[4]; };      // 16 bytes at any address

@@ -130,9 +130,9 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         if (ll == 15) {
             uint32_t b = 255;
             if (KNOWN) { do { b = win.peek(ip); ip++; ll += (int)b; if (ll > (1 << 30)) return -ip; } while (b == 255); }
-            else       { while (ip < iend && b == 255) { b = win.peek(ip); ip++; ll += (int)b; } }
+            else       { while (ip < iend && b == 255) { b = win.peek(ip); ip++; ll += (int)b; ll = ll > (1 << 30) ? (1 << 30) : ll; } }   // saturate: the reference counts in size_t
         }
-        const int lit_end = op + ll;
+        const int lit_end = (int)((int64_t)op + ll > 0x7FFFFFFF ? 0x7FFFFFFF : op + ll);
 
         // ---- last sequence (literals only): lz4.c:851-858 / :965-975 ----
         const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || ip + ll > iend - 8);
@@ -165,12 +165,12 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                 while ((b = win.peek(p)) == 255) { ml += 255; p++; if (ml > (1 << 30)) return -p; }
                 ml += (int)b; p++;
             } else {
-                while (p < iend - (kLastLiterals + 1)) { const uint32_t b = win.peek(p); p++; ml += (int)b; if (b != 255) break; }
+                while (p < iend - (kLastLiterals + 1)) { const uint32_t b = win.peek(p); p++; ml += (int)b; ml = ml > (1 << 30) ? (1 << 30) : ml; if (b != 255) break; }
             }
         }
         ml += kMinMatch;
+        if ((int64_t)lit_end + ml > (int64_t)oend - kLastLiterals) return -p;    // lz4.c:893 / :1024
         const int match_end = lit_end + ml;
-        if (match_end > oend - kLastLiterals) return -p;    // lz4.c:893 / :1024
 
         // ---- materialise the sequence ----
         if (short_lit && ll + ml <= 64) {

@@ -30,7 +30,6 @@
 //     the last bytes of the input, offset 0, errors, the final literal run.
 #pragma once
 #include "lz4hip_common.hpp"
-#include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
 
 namespace lz4hip {
 
@@ -207,14 +206,14 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                         while ((b = (p < iend ? src[p] : 0u)) == 255) { ml += 255; p++; if (ml > (1 << 30)) { err = -p; break; } }
                         ml += (int)b; p++;
                     } else {
-                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; if (b != 255) break; }
+                        while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; ml += (int)b; ml = ml > (1 << 30) ? (1 << 30) : ml; if (b != 255) break; }
                     }
                 }
             }
             ml += kMinMatch;
             if (err != 0) {}
             else if (op - off < 0) err = -(ip + 2);
-            else if (op + ml > oend - kLastLiterals) err = -p;
+            else if ((int64_t)op + ml > (int64_t)oend - kLastLiterals) err = -p;
             ip = p;
             pend = kNeedMatch;
             SLIDE_WINDOW(ip);
@@ -240,11 +239,11 @@ LZ4HIP_DEVICE int chunked_decode_block(unsigned char* lds, int lane, bool active
                 if (ll == 15) {
                     uint32_t b = 255;
                     if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; ll += (int)b; if (ll > (1 << 30)) { err = -pos; ll = 0; break; } } while (b == 255); }
-                    else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; } }
+                    else       { while (pos < iend && b == 255) { b = src[pos]; pos++; ll += (int)b; ll = ll > (1 << 30) ? (1 << 30) : ll; } }   // saturate: the reference counts in size_t
                 }
             }
             const bool in_win = win_ok && ll <= 11;                  // literals, offset and first match-length byte are in x0..x3
-            const int lit_end = op + ll;
+            const int lit_end = (int)((int64_t)op + ll > 0x7FFFFFFF ? 0x7FFFFFFF : op + ll);
             const bool last = KNOWN ? (lit_end > oend - 8) : (lit_end > oend - kMfLimit || pos + ll > iend - 8);
             const int lit_mode = in_win ? (int)kReg : (pos + ll + 16 <= iend ? (int)kGlobal : (int)kSlowLit);
             gptr = lit_mode == kGlobal ? src + pos : gptr;

@@ -193,8 +193,7 @@ tail:
 
 // One wavefront (= one workgroup of 64 threads) per block; 16 KiB of dynamic LDS per workgroup,
 // so up to 10 blocks are resident per CU.
-// only_generic != 0: handle just the blocks of LZ4_64KLIMIT bytes and more (the rest of the batch is encoded
-// by the lane-per-block state machine, lz4hip_encode_sm.hpp).
+// only_generic != 0: handle just the blocks of LZ4_64KLIMIT bytes and more.
 __global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int only_generic)
 {
     LZ4HIP_DYN_LDS(lds);

@@ -14,7 +14,7 @@
 // the slab is sized by residency, not by the batch.
 #pragma once
 #include "lz4hip_common.hpp"
-#include "lz4hip_decode_lane.hpp"   // load_u64 / store_u64
+
 #include "lz4hip_encode.hpp"        // FastTable
 
 namespace lz4hip {

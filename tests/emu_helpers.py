@@ -34,7 +34,7 @@ def pack(rows, pad=16):
     return buf, np.array([len(r) for r in rows], np.int32)
 
 
-def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=False, auto=False, staged=0, chunked=0):
+def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=False, chunked=0):
     src, sl = pack(comps)
     if src_lens is not None:
         sl = np.array(src_lens, np.int32)
@@ -45,13 +45,9 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, lane=
     args = (int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(comps)))
     if chunked:
         lib().emu_decode_chunked(*args, 0, chunked)
-    elif staged:
-        lib().emu_decode_staged(*args, 0, staged)
     elif auto:        # the library's default: the batch is partitioned between the two mappings
         lib().emu_decode_chunked(*args, 2, 256)
         lib().emu_decode(*args, waves_per_group, 1)
-    elif lane:
-        lib().emu_decode_lane(*args, 0)
     else:
         lib().emu_decode(*args, waves_per_group, 0)
     return res, dst
@@ -70,8 +66,6 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
         lib().emu_encode_hc_lane(*args, 1, int(max(len(b) for b in blocks) > 65536))
     elif hc:
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
-    elif lane == "sm":
-        lib().emu_encode_fast_sm(*args, 1)
     elif lane:
         lib().emu_encode_fast_lane(*args, 1)
     else:

@@ -5,12 +5,9 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
-#include "lz4hip_decode_lane.hpp"
-#include "lz4hip_decode_staged.hpp"
 #include "lz4hip_decode_chunked.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
-#include "lz4hip_encode_sm.hpp"
 #include "lz4hip_synth.hpp"
 #ifdef LZ4HIP_HAVE_HC
 #include "lz4hip_hc.hpp"
@@ -40,29 +37,6 @@ void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t
     dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
     if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b, filter); });
     else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b, filter); });
-}
-
-void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter)
-{
-    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
-    dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (known) simt::launch(grid, block, 0, [=] { decode_lane_kernel<true>(b, filter); });
-    else       simt::launch(grid, block, 0, [=] { decode_lane_kernel<false>(b, filter); });
-}
-
-void emu_decode_staged(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                       int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring)
-{
-    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
-    dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (ring == 256) {
-        if (known) simt::launch(grid, block, 64 * 256, [=] { decode_staged_kernel<true, 256>(b, filter); });
-        else       simt::launch(grid, block, 64 * 256, [=] { decode_staged_kernel<false, 256>(b, filter); });
-    } else {
-        if (known) simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<true, 512>(b, filter); });
-        else       simt::launch(grid, block, 64 * 512, [=] { decode_staged_kernel<false, 512>(b, filter); });
-    }
 }
 
 void emu_decode_chunked(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
@@ -112,18 +86,6 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* tables = ws.data() + 256;
     simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables); });
-}
-
-void emu_encode_fast_sm(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
-{
-    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
-    static std::vector<uint8_t> ws;
-    ws.assign(256 + (size_t)groups * 64 * kSmTableBytes, 0);          // the launch zeroes the slab
-    unsigned long long* counter = (unsigned long long*)ws.data();
-    uint8_t* tables = ws.data() + 256;
-    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_sm_kernel(b, counter, tables); });
-    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, 1); });
 }
 
 #ifdef LZ4HIP_HAVE_HC

@@ -4,6 +4,8 @@ encode -> decode round trip is the identity, results == lengths, checksum of che
 import numpy as np
 import pytest
 
+from conftest import ForcedMapping
+
 pytestmark = pytest.mark.gpu
 
 
@@ -30,21 +32,21 @@ def test_device_generators_match_cpu_twins(torch_cuda, oracle):
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
 @pytest.mark.parametrize("hc", [False, True])
-@pytest.mark.parametrize("decoder", ["wave", "lane", "staged", "chunked"])
-def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc, decoder, monkeypatch):
+@pytest.mark.parametrize("decoder", ["wave", "lane"])
+def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc, decoder):
     torch = torch_cuda
     from lz4net_amd import batch
-    monkeypatch.setenv("LZ4HIP_DECODER", decoder)
     n = 4096 if not hc else 512
     raw = batch.synth(dist, 2024, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
     clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=hc)
     back = torch.empty_like(raw)
-    used = batch.decode(comp, clen, back, batch.BLOCK, known_output_size=True)
-    assert bool((clen > 0).all()) and bool((used == clen).all())
-    assert batch.count_mismatches(raw, back, batch.BLOCK) == 0
-    produced = batch.decode(comp, clen, back.zero_(), batch.BLOCK, known_output_size=False)
-    assert bool((produced == batch.BLOCK).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    with ForcedMapping("LZ4HIP_DECODER", decoder):
+        used = batch.decode(comp, clen, back, batch.BLOCK, known_output_size=True)
+        assert bool((clen > 0).all()) and bool((used == clen).all())
+        assert batch.count_mismatches(raw, back, batch.BLOCK) == 0
+        produced = batch.decode(comp, clen, back.zero_(), batch.BLOCK, known_output_size=False)
+        assert bool((produced == batch.BLOCK).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
     # spot-check compressed bytes against the oracle on a deterministic sample
     lens = clen.cpu().numpy()
     for i in list(range(0, n, max(n // 16, 1))) + [n - 1]:
@@ -136,13 +138,13 @@ def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
     epoch-stamped table wraps at least once; sampled blocks must be the oracle's bytes and all must round-trip."""
     torch = torch_cuda
     from lz4net_amd import batch
-    monkeypatch.setenv("LZ4HIP_ENCODER", "lane")
     monkeypatch.setenv("LZ4HIP_ENCODER_WAVES_PER_CU", "1")
     n, length = 1 << 20, 256
     bound = length + length // 255 + 16
     raw = batch.synth(2, 31, 0, n, length=length)
     comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
-    clen = batch.encode(raw, length, comp, bound)
+    with ForcedMapping("LZ4HIP_ENCODER", "lane"):
+        clen = batch.encode(raw, length, comp, bound)
     back = torch.empty_like(raw)
     used = batch.decode(comp, clen, back, length)
     assert bool((clen > 0).all()) and bool((used == clen).all())
@@ -153,14 +155,13 @@ def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
         assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
 
 
-@pytest.mark.parametrize("decoder", ["wave", "chunked"])
-def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder, monkeypatch):
+@pytest.mark.parametrize("decoder", ["wave", "lane"])
+def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder):
     """Destination rows at odd addresses and an odd stride, sources at odd addresses too: the 16-byte stores of both
     decoder mappings (cooperative 64-byte flush of the lane mapping, register fills of the wavefront mapping) must
     not depend on alignment, and must not touch the bytes between the rows."""
     torch = torch_cuda
     from lz4net_amd import batch
-    monkeypatch.setenv("LZ4HIP_DECODER", decoder)
     n = 2048
     for dist in (0, 2, 3):
         raw = batch.synth(dist, 5, 0, n)
@@ -173,7 +174,9 @@ def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder, monkeypatch):
         dstride = batch.BLOCK + 13
         dbuf = torch.full((n * dstride + 64,), 0xC3, dtype=torch.uint8, device="cuda")
         back = dbuf[3:3 + n * dstride].view(n, dstride)
-        used = batch.decode(comp, clen, back, batch.BLOCK)
+        with ForcedMapping("LZ4HIP_DECODER", decoder):
+            used = batch.decode(comp, clen, back, batch.BLOCK)
+            torch.cuda.synchronize()
         assert bool((used == clen).all())
         assert bool((back[:, :batch.BLOCK] == raw).all()), (decoder, dist)
         assert bool((back[:, batch.BLOCK:] == 0xC3).all()) and bool((dbuf[:3] == 0xC3).all())

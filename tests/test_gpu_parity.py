@@ -54,12 +54,14 @@ def test_golden_synth_vectors(gpu, oracle):
             assert sha(dst[i, :res[i]]) == e[ksha], (i, hc, e["dist"], e["n"])
 
 
-@pytest.fixture(params=["wave", "lane", "sm"])
+from conftest import ForcedMapping, _forced_fixture  # noqa: E402
+
+
+@pytest.fixture(params=["wave", "lane"])
 def encoder(request):
-    """Both block->hardware mappings of the fast encoder (lz4hip_encode.hpp / lz4hip_encode_lane.hpp)."""
-    os.environ["LZ4HIP_ENCODER"] = request.param
-    yield request.param
-    del os.environ["LZ4HIP_ENCODER"]
+    """Both block->hardware mappings of the fast encoder (lz4hip_encode.hpp / lz4hip_encode_lane.hpp); the fixture
+    asserts through lz4hip_dispatch_counts that the mapping named is the one that ran."""
+    yield from _forced_fixture("LZ4HIP_ENCODER", request.param)
 
 
 def test_fast_encode_bit_exact(gpu, oracle, encoder):
@@ -74,9 +76,7 @@ def test_fast_encode_bit_exact(gpu, oracle, encoder):
 
 @pytest.fixture(params=["wave", "lane"])
 def hc_mapping(request):
-    os.environ["LZ4HIP_HC"] = request.param
-    yield request.param
-    del os.environ["LZ4HIP_HC"]
+    yield from _forced_fixture("LZ4HIP_HC", request.param)
 
 
 def test_hc_encode_bit_exact(gpu, oracle, hc_mapping):
@@ -102,12 +102,12 @@ def test_limited_output(gpu, oracle, encoder, hc_mapping):
                 assert (dst[i, caps[i]:] == 0xA5).all(), (i, hc, delta, "wrote past the capacity")
 
 
-@pytest.fixture(params=["wave", "lane", "staged", "chunked"])
+@pytest.fixture(params=["wave", "lane"])
 def decoder(request):
-    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane.hpp)."""
-    os.environ["LZ4HIP_DECODER"] = request.param
-    yield request.param
-    del os.environ["LZ4HIP_DECODER"]
+    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_chunked.hpp).  The override
+    holds for every batch size, and the fixture asserts through lz4hip_dispatch_counts that the mapping named ran
+    and the other one did not."""
+    yield from _forced_fixture("LZ4HIP_DECODER", request.param)
 
 
 def test_decode_known_and_unknown(gpu, oracle, decoder):
@@ -333,7 +333,6 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatc
     """GPU twin of the emulator test of the same name: 256 identical crafted blocks through the lane mapping (every
     lane flushes in the same iteration; matches of every length 4..40 at offsets inside / just behind / far behind
     the LDS ring, periodic matches, literal runs of 0..80 bytes), known and unknown output size."""
-    monkeypatch.setenv("LZ4HIP_DECODER", "chunked")
     rng = np.random.default_rng(23)
     data = bytearray(rng.integers(0, 256, 7000, dtype=np.uint8).tobytes())
     for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 500, 4097, 6000):
@@ -347,10 +346,11 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatc
     block = np.frombuffer(bytes(data), dtype=np.uint8)
     comp = oracle.compress(block)
     n = 256
-    used, back = gpu.decode([comp] * n, [block.size] * n, known=True)
-    assert (used == len(comp)).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
-    produced, back = gpu.decode([comp] * n, [block.size + 9] * n, known=False)
-    assert (produced == block.size).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
+    with ForcedMapping("LZ4HIP_DECODER", "lane"):
+        used, back = gpu.decode([comp] * n, [block.size] * n, known=True)
+        assert (used == len(comp)).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
+        produced, back = gpu.decode([comp] * n, [block.size + 9] * n, known=False)
+        assert (produced == block.size).all() and all(np.array_equal(back[i, :block.size], block) for i in range(n))
 
 
 def test_decode_arbitrary_streams(gpu, oracle, decoder):

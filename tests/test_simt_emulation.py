@@ -12,9 +12,7 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
-    if isinstance(m, str):
-        return dict(chunked=int(m[7:])) if m.startswith("chunked") else dict(staged=int(m[6:]))
-    return dict(lane=m)
+    return dict(chunked=int(m[7:])) if isinstance(m, str) else {}
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
@@ -31,8 +29,7 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
-                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
 def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
@@ -53,8 +50,7 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
-                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -66,8 +62,7 @@ def test_decode_unknown_size(oracle, lane):
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True, "staged256", "staged512", "chunked128", "chunked256"],
-                         ids=["wave-per-block", "lane-per-block", "lane+ring256", "lane+ring512", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
@@ -97,7 +92,7 @@ def test_decode_error_codes_match_oracle(oracle, lane):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True, "sm"], ids=["wave-per-block", "lane-per-block", "lane-state-machine"])
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
 def test_encode_fast_bit_exact(oracle, lane):
     blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6) if lane else (5,))
     res, dst = emu.encode(blocks, lane=lane)
@@ -108,7 +103,7 @@ def test_encode_fast_bit_exact(oracle, lane):
         assert (dst[i, compress_bound(a.size):] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True, "sm"], ids=["wave-per-block", "lane-per-block", "lane-state-machine"])
+@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
 def test_encode_fast_limited_output(oracle, lane):
     # original/fuzzer.c:212-227: exact capacity succeeds, one byte less returns 0, canary untouched
     blocks = _blocks(oracle, sizes=(13, 300, 4096, 65536))
@@ -231,7 +226,7 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(oracle):
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
-@pytest.mark.parametrize("lane", [False, True, "chunked128"], ids=["wave-per-block", "lane-per-block", "chunked128"])
+@pytest.mark.parametrize("lane", [False, "chunked128"], ids=["wave-per-block", "chunked128"])
 def test_decode_arbitrary_streams(oracle, lane):
     """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
     them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching
