@@ -30,6 +30,31 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH
 DIST_NAMES = {0: "D0-zeros", 1: "D1-incompressible", 2: "D2-fuzzer(original/fuzzer.c)", 3: "D3-records"}
 
 
+def csrc_sha() -> str:
+    """Hash of the kernel sources: committed PMC traffic figures are only quoted for the code they were measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lz4net_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kind: str, dist: int, blocks: int):
+    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
+    from profiles/r02/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel sources and
+    this workload; otherwise None (a stale number would be a lie)."""
+    f = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    if not os.path.exists(f):
+        return None, None
+    d = json.load(open(f))
+    e = d.get(kind)
+    if d.get("csrc_sha") != csrc_sha() or not e or e.get("dist") != dist or e.get("blocks") != blocks:
+        return None, None
+    return int(e["bytes_per_launch"]), f"profiles/r02/pmc_traffic.json[{kind}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch; csrc {d['csrc_sha']})"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +65,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--no-extras", action="store_true", help="skip the other distributions / encoder timings")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--hc-only", action="store_true", help="of the extras run only the LZ4HC leg (profiling runs)")
     ap.add_argument("--hc-blocks", type=int, default=1 << 18, help="blocks for the LZ4HC extra (SURVEY 8d C4: 2^18; 0 = skip)")
     ap.add_argument("--decoder", choices=["auto", "lane", "wave"], default="auto",
                     help="block->hardware mapping of the decoder (auto = library default)")
@@ -88,7 +114,8 @@ class Workload:
         k = min(n, 16384)
         batch.encode(self.raw[:k], batch.BLOCK, self.comp[:k], batch.BOUND, result=self.clen[:k])
         torch.cuda.synchronize()
-        self.encode_ms = event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
+        self.encode_ms = min(event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
+                             for _ in range(2))
         self.comp_bytes = int(self.clen.to(torch.int64).sum().item())
         assert bool((self.clen > 0).all()), "encoder reported failure on a block"
 
@@ -236,7 +263,9 @@ def main():
     }
     extras[DIST_NAMES[args.dist]] = head
     alg_bytes_local, mean_kernel_ms = wl.algorithmic_bytes, sum(kernel_ms) / len(kernel_ms)
-    if world == 1 and not args.no_extras and args.decoder == "auto":
+    enc_roof = {"ms": wl.encode_ms, "alg": wl.algorithmic_bytes, "blocks": n}      # BASELINE configs[2]
+    hc_roof = None                                                               # BASELINE configs[3]
+    if world == 1 and not args.no_extras and not args.hc_only and args.decoder == "auto":
         for name in ("lane", "wave"):
             os.environ["LZ4HIP_DECODER"] = name
             wl.back.zero_()
@@ -249,7 +278,7 @@ def main():
     if world == 1 and not args.no_extras:
         del wl
         torch.cuda.empty_cache()
-        for d in range(4):
+        for d in ([] if args.hc_only else range(4)):
             if d == args.dist:
                 continue
             w = Workload(torch, batch, d, seed, 0, n, dst_pad=args.dst_pad)
@@ -295,6 +324,7 @@ def main():
             clen = clen_holder["c"]
             back = torch.empty_like(raw)
             used = batch.decode(comp, clen, back, batch.BLOCK)
+            hc_roof = {"ms": ms, "alg": m * batch.BLOCK + int(clen.to(torch.int64).sum().item()) + 8 * m, "blocks": m}
             extras["LZ4HC " + DIST_NAMES[args.dist]] = {
                 "encode_hc_GBps": round(m * batch.BLOCK / (ms / 1e3) / 1e9, 3),
                 "ratio": round(float(clen.double().sum().item()) / (m * batch.BLOCK), 4), "blocks": m,
@@ -302,48 +332,49 @@ def main():
                 "roundtrip_ok": bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0,
             }
             del raw, comp, back
-        # ---- the HBM roof measured on this box (quote the 8 TB/s spec AND what a copy reaches) ----
-        torch.cuda.empty_cache()
-        words = (4 << 30) // 8
-        xa = torch.empty(words, dtype=torch.int64, device="cuda")
-        xb = torch.empty(words, dtype=torch.int64, device="cuda")
-        xa.fill_(1); xb.copy_(xa); torch.cuda.synchronize()
-        t_fill = min(event_ms(lambda: xa.fill_(2), torch) for _ in range(3))
-        t_copy = min(event_ms(lambda: xb.copy_(xa), torch) for _ in range(3))
-        extras["hbm_measured"] = {
-            "fill_GBps_write_only": round(words * 8 / (t_fill / 1e3) / 1e9, 1),
-            "copy_GBps_read_plus_write": round(2 * words * 8 / (t_copy / 1e3) / 1e9, 1),
-            "bytes": words * 8, "note": "torch fill_/copy_ of a 4 GiB buffer, best of 3 (the spec-sheet 8000 GB/s is what roofline.peak quotes)",
-        }
-        del xa, xb
-        torch.cuda.empty_cache()
-        # ---- PCIe-inclusive rate of the host-pointer batch entry point (never `value`) ----
-        import ctypes as C
-        import numpy as np
-        m = min(4096, n)
-        raw_d = batch.synth(args.dist, seed, 0, m)
-        comp_d = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
-        clen_h = batch.encode(raw_d, batch.BLOCK, comp_d, batch.BOUND).cpu().numpy().astype(np.int32)
-        comp_h, raw_h = comp_d.cpu().numpy(), raw_d.cpu().numpy()
-        back_h = np.zeros_like(raw_h)
-        caps_h = np.full(m, batch.BLOCK, np.int32)
-        res_h = np.zeros(m, np.int32)
-        hb = _lib.Batch(src=comp_h.ctypes.data, src_off=None, src_stride=comp_h.strides[0], src_len=clen_h.ctypes.data,
-                        dst=back_h.ctypes.data, dst_off=None, dst_stride=back_h.strides[0], dst_cap=caps_h.ctypes.data,
-                        dst_cap_all=0, src_len_all=0, result=res_h.ctypes.data, n_blocks=m)
-        _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
-        t_host = None
-        for _ in range(3):
-            t1 = time.perf_counter()
+        if not args.hc_only:
+            # ---- the HBM roof measured on this box (quote the 8 TB/s spec AND what a copy reaches) ----
+            torch.cuda.empty_cache()
+            words = (4 << 30) // 8
+            xa = torch.empty(words, dtype=torch.int64, device="cuda")
+            xb = torch.empty(words, dtype=torch.int64, device="cuda")
+            xa.fill_(1); xb.copy_(xa); torch.cuda.synchronize()
+            t_fill = min(event_ms(lambda: xa.fill_(2), torch) for _ in range(3))
+            t_copy = min(event_ms(lambda: xb.copy_(xa), torch) for _ in range(3))
+            extras["hbm_measured"] = {
+                "fill_GBps_write_only": round(words * 8 / (t_fill / 1e3) / 1e9, 1),
+                "copy_GBps_read_plus_write": round(2 * words * 8 / (t_copy / 1e3) / 1e9, 1),
+                "bytes": words * 8, "note": "torch fill_/copy_ of a 4 GiB buffer, best of 3 (the spec-sheet 8000 GB/s is what roofline.peak quotes)",
+            }
+            del xa, xb
+            torch.cuda.empty_cache()
+            # ---- PCIe-inclusive rate of the host-pointer batch entry point (never `value`) ----
+            import ctypes as C
+            import numpy as np
+            m = min(4096, n)
+            raw_d = batch.synth(args.dist, seed, 0, m)
+            comp_d = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+            clen_h = batch.encode(raw_d, batch.BLOCK, comp_d, batch.BOUND).cpu().numpy().astype(np.int32)
+            comp_h, raw_h = comp_d.cpu().numpy(), raw_d.cpu().numpy()
+            back_h = np.zeros_like(raw_h)
+            caps_h = np.full(m, batch.BLOCK, np.int32)
+            res_h = np.zeros(m, np.int32)
+            hb = _lib.Batch(src=comp_h.ctypes.data, src_off=None, src_stride=comp_h.strides[0], src_len=clen_h.ctypes.data,
+                            dst=back_h.ctypes.data, dst_off=None, dst_stride=back_h.strides[0], dst_cap=caps_h.ctypes.data,
+                            dst_cap_all=0, src_len_all=0, result=res_h.ctypes.data, n_blocks=m)
             _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
-            dt = time.perf_counter() - t1
-            t_host = dt if t_host is None else min(t_host, dt)
-        extras["host_pointer_batch_pcie_inclusive"] = {
-            "decode_GBps": round(m * batch.BLOCK / t_host / 1e9, 2), "blocks": m,
-            "ok": bool((res_h == clen_h).all()) and bool(np.array_equal(back_h, raw_h)),
-            "note": "lz4hip_decode_batch_host on pageable host arrays: H2D + kernel + D2H, best of 3 (reported beside, never as, `value`)",
-        }
-        del raw_d, comp_d
+            t_host = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
+                dt = time.perf_counter() - t1
+                t_host = dt if t_host is None else min(t_host, dt)
+            extras["host_pointer_batch_pcie_inclusive"] = {
+                "decode_GBps": round(m * batch.BLOCK / t_host / 1e9, 2), "blocks": m,
+                "ok": bool((res_h == clen_h).all()) and bool(np.array_equal(back_h, raw_h)),
+                "note": "lz4hip_decode_batch_host on pageable host arrays: H2D + kernel + D2H, best of 3 (reported beside, never as, `value`)",
+            }
+            del raw_d, comp_d
 
     if rank != 0:
         if world > 1:
@@ -358,19 +389,30 @@ def main():
         except Exception as e:   # the bench line must still be printed
             cpu = {"error": repr(e)}
 
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process, so it is
-    # taken from the committed rocprofv3 --pmc summary of this exact workload (tools/pmc_decoder.sh: separate
-    # FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes, per launch); null when the configuration differs.
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_decode_chunked_kernel_D2_2p20blocks_2launches.json")
-    if world == 1 and args.dist == 2 and n == (1 << 20) and args.decoder == "auto" and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        traffic = int((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / pmc["launches_summed"])
+    # HBM-side traffic of the kernels: PMC counters cannot be collected inside this process, so they come from the
+    # committed rocprofv3 --pmc summary (profiles/r02/pmc_traffic.json, tools/pmc_traffic.sh) -- keyed on a hash of
+    # lz4net_amd/csrc/ and on the workload; null when either differs.
+    traffic, traffic_src = (None, None)
+    if world == 1 and args.decoder == "auto":
+        traffic, traffic_src = committed_traffic("decode", args.dist, n)
     total_raw = n * batch.BLOCK * world
     ms_per_step = elapsed / args.steps * 1e3
     achieved = alg_bytes_local / (mean_kernel_ms / 1e3) / 1e9
+    wave_mapped = args.decoder == "wave" or (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
+
+    def side_roofline(r, kind, kernel):
+        if r is None:
+            return None
+        a = r["alg"] / (r["ms"] / 1e3) / 1e9
+        t, tsrc = committed_traffic(kind, args.dist, r["blocks"]) if world == 1 else (None, None)
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": r["alg"], "kernel_ms": round(r["ms"], 3), "blocks": r["blocks"],
+                "uncompressed_GBps": round(r["blocks"] * batch.BLOCK / (r["ms"] / 1e3) / 1e9, 2)}
+
     line = {
-        "metric": "uncompressed GB/s, batched 64KiB-block decode (known output size), per-step over the whole resident batch",
+        "metric": "uncompressed GB/s, batched 64KiB-block encode+decode: value = decode (known output size) per step over the "
+                  "whole resident batch; fast encode and LZ4HC encode of the same data in roofline_encode / roofline_hc",
         "value": round(total_raw / (elapsed / args.steps) / 1e9, 2),
         "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -384,16 +426,18 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if args.decoder == "wave" or
-                       (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
-                       else "lz4hip::decode_chunked_kernel<true,128> (one lane per block, LDS output ring)"),
+            "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if wave_mapped
+                       else "lz4hip::decode_lane_kernel<true,...> (one lane per block, LDS input staging + output ring)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01/pmc_traffic_decode_chunked_kernel_D2_2p20blocks_2launches.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch)" if traffic else None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),
         },
+        # BASELINE configs[2] / [3]: one launch over the batch, HIP events on the launch stream, same algorithmic bytes
+        "roofline_encode": side_roofline(enc_roof, "encode_fast", "lz4hip::encode_fast_lane_kernel (LZ4_compress64kCtx, one lane per block)"),
+        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::encode_hc_lane_kernel (LZ4_compressHCCtx, one lane per block)"),
         "cpu_baseline": cpu,
         "verified": all_ok,
+        "csrc_sha": csrc_sha(),
         "extras": extras,
     }
     print(json.dumps(line))

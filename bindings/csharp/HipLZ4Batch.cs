@@ -33,6 +33,17 @@ namespace LZ4hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
         private static extern unsafe int lz4hip_decode_batch_host(Batch* b, int knownOutputSize);
 
+        // Sharded over the GPUs of the node: block i -> the (i mod N)-th device of deviceMask (bit d = device d,
+        // 0 = all visible devices); include/lz4hip.h, SURVEY.md 8e.  No launcher, no collective.
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+        private static extern unsafe int lz4hip_encode_batch_host_multi(Batch* b, int mode, ulong deviceMask);
+
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+        private static extern unsafe int lz4hip_decode_batch_host_multi(Batch* b, int knownOutputSize, ulong deviceMask);
+
+        /// <summary>Devices the batch calls shard over (bit d = HIP device d; 0 = every visible device).</summary>
+        public static ulong DeviceMask = 0;
+
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
         private static extern int lz4hip_compressBound(int isize);
 
@@ -61,7 +72,7 @@ namespace LZ4hip
             fixed (int* sl = lens, dc = caps, res = results)
             {
                 var b = new Batch { src = ps, src_off = so, src_len = sl, dst = pd, dst_off = dof, dst_cap = dc, result = res, n_blocks = n };
-                Check(lz4hip_encode_batch_host(&b, highCompression ? ModeHC : ModeFast));
+                Check(lz4hip_encode_batch_host_multi(&b, highCompression ? ModeHC : ModeFast, DeviceMask));
             }
             var output = new byte[n][];
             for (int i = 0; i < n; i++)
@@ -94,7 +105,7 @@ namespace LZ4hip
             fixed (int* sl = lens, dc = outputLengths, res = results)
             {
                 var b = new Batch { src = ps, src_off = so, src_len = sl, dst = pd, dst_off = dof, dst_cap = dc, result = res, n_blocks = n };
-                Check(lz4hip_decode_batch_host(&b, 1));
+                Check(lz4hip_decode_batch_host_multi(&b, 1, DeviceMask));
             }
             var output = new byte[n][];
             for (int i = 0; i < n; i++)

@@ -89,11 +89,19 @@ int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, v
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode);
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
 
+/* Host-resident batches sharded over several GPUs of the node: block i is processed by the (i mod N)-th device
+ * selected by device_mask (bit d = HIP device d; 0 = every visible device) -- the round-robin partition of
+ * SURVEY.md 8e.  One worker thread and one staging pipeline per device, no inter-device traffic; per-block results
+ * and payloads land in the caller's arrays in global block order.  This is what a C# caller (HipLZ4Batch,
+ * bindings/csharp) uses to spread LZ4Codec work over the 8 GPUs of a node without any launcher. */
+int lz4hip_encode_batch_host_multi(const lz4hip_batch_t* b, int mode, uint64_t device_mask);
+int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_size, uint64_t device_mask);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------
  * Launch counters per kernel family since the library was loaded: which block->hardware mapping a call
  * actually used (the GPU tests assert these).  Copies min(n, LZ4HIP_K_COUNT) counters, returns LZ4HIP_K_COUNT. */
 #define LZ4HIP_K_DECODE_WAVE 0   /* lz4hip_decode.hpp:         one wavefront per block */
-#define LZ4HIP_K_DECODE_LANE 1   /* lz4hip_decode_chunked.hpp: one lane per block      */
+#define LZ4HIP_K_DECODE_LANE 1   /* lz4hip_decode_lane.hpp:    one lane per block      */
 #define LZ4HIP_K_ENCODE_WAVE 2
 #define LZ4HIP_K_ENCODE_LANE 3
 #define LZ4HIP_K_HC_WAVE     4

@@ -45,6 +45,8 @@ SYMBOLS = [
     ("lz4hip_decode_batch_device", C.c_int, [C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("lz4hip_encode_batch_host", C.c_int, [C.POINTER(Batch), C.c_int]),
     ("lz4hip_decode_batch_host", C.c_int, [C.POINTER(Batch), C.c_int]),
+    ("lz4hip_encode_batch_host_multi", C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint64]),
+    ("lz4hip_decode_batch_host_multi", C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint64]),
     ("lz4hip_synth_device", C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     ("lz4hip_checksum_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lz4hip_compare_device", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),

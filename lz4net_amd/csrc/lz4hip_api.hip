@@ -6,7 +6,7 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
-#include "lz4hip_decode_chunked.hpp"
+#include "lz4hip_decode_lane.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
@@ -37,6 +37,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // A lone wavefront of the lane mapping needs milliseconds for its 64 blocks, so the mapping only pays once the
 // batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
+constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 
 int fail(int code, const std::string& what)
 {
@@ -265,27 +266,34 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
     // Two mappings of the same decoder (lz4hip_decode.hpp: one wavefront per block, coalesced wide copies;
-    // lz4hip_decode_chunked.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
+    // lz4hip_decode_lane.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
     // partitioned per block by block_selected(): two launches, each skipping the other's blocks.
     // Small batches cannot fill the lanes and use the wavefront mapping only.
     // LZ4HIP_DECODER=wave|lane forces one mapping for EVERY block, whatever the batch size (tests, A-B runs).
     const char* force = getenv("LZ4HIP_DECODER");
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
     if (force && force[0] == 'w') { wave_filter = kAllBlocks; lane_filter = -1; }
-    else if (force && (force[0] == 'l' || force[0] == 'c')) { lane_filter = kAllBlocks; wave_filter = -1; }
+    else if (force && force[0] == 'l') { lane_filter = kAllBlocks; wave_filter = -1; }
     else if (d.n_blocks < kLaneDecodeMinBlocks) { wave_filter = kAllBlocks; lane_filter = -1; }
     if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        int ring = kChunkedRingBytes;
+        // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU).
+        // LZ4HIP_RING_BYTES / LZ4HIP_STAGE_BYTES / LZ4HIP_LANE_LDS_PAD: tuning runs (profiles/r02/decoder_ab_*.txt).
+        int ring = kLaneDecodeRingBytes, stage = kLaneDecodeStageBytes;
+        unsigned pad = 0;
         if (const char* e = getenv("LZ4HIP_RING_BYTES")) ring = atoi(e);
-#define LZ4HIP_LAUNCH_CHUNKED(R)                                                                                      \
-        do {                                                                                                          \
-            if (known) hipLaunchKernelGGL((decode_chunked_kernel<true, R>), dim3(grid), dim3(64), 0, stream, d, lane_filter);   \
-            else       hipLaunchKernelGGL((decode_chunked_kernel<false, R>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) stage = atoi(e);
+        if (const char* e = getenv("LZ4HIP_LANE_LDS_PAD")) pad = (unsigned)atoi(e);
+#define LZ4HIP_LAUNCH_LANE(R, SB)                                                                                               \
+        do {                                                                                                                    \
+            if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), pad, stream, d, lane_filter);   \
+            else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), pad, stream, d, lane_filter);  \
         } while (0)
-        if (ring == 256) LZ4HIP_LAUNCH_CHUNKED(256);
-        else LZ4HIP_LAUNCH_CHUNKED(128);
-#undef LZ4HIP_LAUNCH_CHUNKED
+        if (ring == 128 && stage == 128) LZ4HIP_LAUNCH_LANE(128, 128);
+        else if (ring == 256 && stage == 128) LZ4HIP_LAUNCH_LANE(256, 128);
+        else if (ring == 256) LZ4HIP_LAUNCH_LANE(256, 64);
+        else LZ4HIP_LAUNCH_LANE(128, 64);
+#undef LZ4HIP_LAUNCH_LANE
         count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {
@@ -501,6 +509,75 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     return err;
 }
 
+// Host-resident batch sharded over the devices of `device_mask` (bit d = HIP device d; 0 = every visible device):
+// block i belongs to the (i mod N)-th selected device -- the partition of SURVEY.md 8e / BASELINE configs[4] -- one
+// worker thread per device, each with its own staging pipeline (run_host_batch on that device); no device ever sees
+// another device's blocks and nothing is exchanged between them.  Results land in the caller's arrays in global order.
+template <class Run>
+int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run)
+{
+    int rc = check_batch(hb);
+    if (rc) return rc;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(LZ4HIP_E_DEVICE, "no HIP device");
+    std::vector<int> devs;
+    for (int d = 0; d < visible && d < 64; d++)
+        if (device_mask == 0 || ((device_mask >> d) & 1ull)) devs.push_back(d);
+    if (devs.empty()) return fail(LZ4HIP_E_ARGUMENT, "device_mask selects no visible device");
+    const int64_t n = hb->n_blocks;
+    if (n == 0) return 0;
+    const int nd = (int)devs.size();
+    int prev_dev = 0;
+    HIP_TRY(hipGetDevice(&prev_dev));
+
+    struct Shard {
+        std::vector<int64_t> src_off, dst_off;
+        std::vector<int32_t> src_len, dst_cap, result;
+        lz4hip_batch_t b;
+        int rc = 0;
+        std::string err;
+    };
+    std::vector<Shard> shards((size_t)nd);
+    for (int k = 0; k < nd; k++) {
+        Shard& sh = shards[(size_t)k];
+        const int64_t cnt = n > k ? (n - k + nd - 1) / nd : 0;
+        sh.src_off.resize((size_t)cnt); sh.dst_off.resize((size_t)cnt);
+        sh.src_len.resize((size_t)cnt); sh.dst_cap.resize((size_t)cnt); sh.result.assign((size_t)cnt, 0);
+        for (int64_t j = 0; j < cnt; j++) {
+            const int64_t i = j * nd + k;
+            sh.src_off[(size_t)j] = hb->src_off ? hb->src_off[i] : i * hb->src_stride;
+            sh.dst_off[(size_t)j] = hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride;
+            sh.src_len[(size_t)j] = hb->src_len ? hb->src_len[i] : hb->src_len_all;
+            sh.dst_cap[(size_t)j] = hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all;
+        }
+        sh.b = *hb;
+        sh.b.src_off = sh.src_off.data(); sh.b.dst_off = sh.dst_off.data();
+        sh.b.src_len = sh.src_len.data(); sh.b.dst_cap = sh.dst_cap.data();
+        sh.b.result = sh.result.data(); sh.b.n_blocks = cnt;
+    }
+    auto work = [&](int k) {
+        Shard& sh = shards[(size_t)k];
+        if (sh.b.n_blocks == 0) return;
+        if (hipSetDevice(devs[(size_t)k]) != hipSuccess) { sh.rc = LZ4HIP_E_DEVICE; sh.err = "hipSetDevice failed"; return; }
+        sh.rc = run_host_batch(&sh.b, dst_len_is_result, run);
+        if (sh.rc) sh.err = g_last_error;                            // thread-local: carry it back to the caller
+    };
+    if (nd == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int k = 0; k < nd; k++) pool.emplace_back(work, k);
+        for (auto& t : pool) t.join();
+    }
+    (void)hipSetDevice(prev_dev);
+    for (int k = 0; k < nd; k++) {
+        const Shard& sh = shards[(size_t)k];
+        if (sh.rc) return fail(sh.rc, "device " + std::to_string(devs[(size_t)k]) + ": " + sh.err);
+        for (int64_t j = 0; j < sh.b.n_blocks; j++) hb->result[j * nd + k] = sh.result[(size_t)j];
+    }
+    return 0;
+}
+
 int single(const char* src, int src_len, char* dst, int dst_cap, int kind /*0 fast,1 hc,2 dec known,3 dec unknown*/)
 {
     if (!src || !dst) return fail(LZ4HIP_E_ARGUMENT, "NULL buffer");
@@ -610,6 +687,18 @@ int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
 {
     return run_host_batch(b, !known_output_size,
                           [known_output_size](const lz4hip_batch_t* db, hipStream_t s) { return launch_decode(db, known_output_size, s); });
+}
+
+int lz4hip_encode_batch_host_multi(const lz4hip_batch_t* b, int mode, uint64_t device_mask)
+{
+    return run_host_batch_multi(b, true, device_mask,
+                                [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); });
+}
+
+int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_size, uint64_t device_mask)
+{
+    return run_host_batch_multi(b, !known_output_size, device_mask,
+                                [known_output_size](const lz4hip_batch_t* db, hipStream_t s) { return launch_decode(db, known_output_size, s); });
 }
 
 int lz4hip_compress_limitedOutput(const char* source, char* dest, int isize, int maxOutputSize)

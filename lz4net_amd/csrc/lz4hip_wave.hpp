@@ -76,6 +76,14 @@ LZ4HIP_DEVICE void store_global16(uint64_t addr, uint32_t a, uint32_t b, uint32_
     *(__attribute__((address_space(1))) u32x4_unaligned*)addr = v;
 }
 
+// 16-byte load from a GLOBAL address rebuilt from integers (global_load_dwordx4: a flat_load would also count on
+// lgkmcnt and make the next LDS access wait for it).
+LZ4HIP_DEVICE void load_global16(uint64_t addr, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+{
+    const u32x4_unaligned v = *(const __attribute__((address_space(1))) u32x4_unaligned*)addr;
+    a = v.x; b = v.y; c = v.z; d = v.w;
+}
+
 // 16 bytes to / from any address, any alignment, as ONE dwordx4 access (a plain 4-byte-aligned struct copy is split
 // into four dword accesses by the compiler).
 LZ4HIP_DEVICE void store16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)

@@ -34,7 +34,7 @@ def pack(rows, pad=16):
     return buf, np.array([len(r) for r in rows], np.int32)
 
 
-def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=False, chunked=0):
+def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=False, lane=0, stage=64):
     src, sl = pack(comps)
     if src_lens is not None:
         sl = np.array(src_lens, np.int32)
@@ -43,10 +43,10 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     dst = np.full((len(comps), ds), 0xA5, np.uint8)
     res = np.full(len(comps), -12345678, np.int32)
     args = (int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(comps)))
-    if chunked:
-        lib().emu_decode_chunked(*args, 0, chunked)
+    if lane:
+        lib().emu_decode_lane(*args, 0, lane, stage)
     elif auto:        # the library's default: the batch is partitioned between the two mappings
-        lib().emu_decode_chunked(*args, 2, 256)
+        lib().emu_decode_lane(*args, 2, 128, 64)
         lib().emu_decode(*args, waves_per_group, 1)
     else:
         lib().emu_decode(*args, waves_per_group, 0)

@@ -22,7 +22,7 @@ def _batch(src, sl, dst, caps, res):
                       dst_cap_all=0, src_len_all=0, result=res.ctypes.data, n_blocks=src.shape[0])
 
 
-def encode(blocks, caps=None, hc=False, canary=64):
+def encode(blocks, caps=None, hc=False, canary=64, device_mask=None):
     src, sl = pack(blocks)
     if caps is None:
         caps = [len(b) + len(b) // 255 + 16 for b in blocks]
@@ -30,11 +30,14 @@ def encode(blocks, caps=None, hc=False, canary=64):
     dst = np.full((len(blocks), max(int(caps.max()), 1) + canary), 0xA5, np.uint8)
     res = np.zeros(len(blocks), np.int32)
     b = _batch(src, sl, dst, caps, res)
-    _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), 1 if hc else 0))
+    if device_mask is None:
+        _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), 1 if hc else 0))
+    else:
+        _lib.check(_lib.lib().lz4hip_encode_batch_host_multi(C.byref(b), 1 if hc else 0, device_mask))
     return res, dst
 
 
-def decode(comps, out_sizes, known=True, src_lens=None, canary=64):
+def decode(comps, out_sizes, known=True, src_lens=None, canary=64, device_mask=None):
     src, sl = pack(comps)
     if src_lens is not None:
         sl = np.array(src_lens, np.int32)
@@ -42,5 +45,8 @@ def decode(comps, out_sizes, known=True, src_lens=None, canary=64):
     dst = np.full((len(comps), max(int(caps.max()), 1) + canary), 0xA5, np.uint8)
     res = np.zeros(len(comps), np.int32)
     b = _batch(src, sl, dst, caps, res)
-    _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(b), 1 if known else 0))
+    if device_mask is None:
+        _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(b), 1 if known else 0))
+    else:
+        _lib.check(_lib.lib().lz4hip_decode_batch_host_multi(C.byref(b), 1 if known else 0, device_mask))
     return res, dst

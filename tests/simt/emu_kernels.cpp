@@ -3,9 +3,12 @@
 // them through a C ABI for tests/test_simt_emulation.py.  Built with g++, never shipped.
 #include "simt_wave.hpp"
 
+static unsigned long long g_iterations = 0;   // loop iterations of the lane decoders (all wavefronts), counted by lane 0
+#define LZ4HIP_ITERATION_HOOK(lane) do { if ((lane) == 0) g_iterations++; } while (0)
+
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
-#include "lz4hip_decode_chunked.hpp"
+#include "lz4hip_decode_lane.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_synth.hpp"
@@ -39,18 +42,21 @@ void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t
     else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b, filter); });
 }
 
-void emu_decode_chunked(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring)
+void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                     int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring, int stage)
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (ring == 128) {
-        if (known) simt::launch(grid, block, chunked_lds_bytes(128), [=] { decode_chunked_kernel<true, 128>(b, filter); });
-        else       simt::launch(grid, block, chunked_lds_bytes(128), [=] { decode_chunked_kernel<false, 128>(b, filter); });
-    } else {
-        if (known) simt::launch(grid, block, chunked_lds_bytes(256), [=] { decode_chunked_kernel<true, 256>(b, filter); });
-        else       simt::launch(grid, block, chunked_lds_bytes(256), [=] { decode_chunked_kernel<false, 256>(b, filter); });
-    }
+#define EMU_LANE(R, SB)                                                                                                        \
+    do {                                                                                                                       \
+        if (known) simt::launch(grid, block, lane_decode_lds_bytes(R, SB), [=] { decode_lane_kernel<true, R, SB>(b, filter); });  \
+        else       simt::launch(grid, block, lane_decode_lds_bytes(R, SB), [=] { decode_lane_kernel<false, R, SB>(b, filter); }); \
+    } while (0)
+    if (ring == 128 && stage == 64) EMU_LANE(128, 64);
+    else if (ring == 128) EMU_LANE(128, 128);
+    else if (stage == 64) EMU_LANE(256, 64);
+    else EMU_LANE(256, 128);
+#undef EMU_LANE
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
@@ -125,4 +131,5 @@ unsigned long long emu_compare(const uint8_t* x, int64_t xs, const uint8_t* y, i
 }
 
 unsigned long long emu_steps() { return simt::rt().steps; }
+unsigned long long emu_iterations(int reset) { const unsigned long long v = g_iterations; if (reset) g_iterations = 0; return v; }
 }

@@ -106,6 +106,13 @@ inline void store_global16(uint64_t addr, uint32_t a, uint32_t b, uint32_t c, ui
     __builtin_memcpy((void*)addr, v, 16);
 }
 
+inline void load_global16(uint64_t addr, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+{
+    uint32_t v[4];
+    __builtin_memcpy(v, (const void*)addr, 16);
+    a = v[0]; b = v[1]; c = v[2]; d = v[3];
+}
+
 inline void store16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     const uint32_t v[4] = { a, b, c, d };

@@ -104,7 +104,7 @@ def test_limited_output(gpu, oracle, encoder, hc_mapping):
 
 @pytest.fixture(params=["wave", "lane"])
 def decoder(request):
-    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_chunked.hpp).  The override
+    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane.hpp).  The override
     holds for every batch size, and the fixture asserts through lz4hip_dispatch_counts that the mapping named ran
     and the other one did not."""
     yield from _forced_fixture("LZ4HIP_DECODER", request.param)
@@ -329,13 +329,13 @@ def test_host_entry_points_from_several_threads(gpu, oracle):
     assert not errors, errors[:5]
 
 
-def test_chunked_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatch):
+def test_lane_decoder_lockstep_lanes_and_copy_lengths(gpu, oracle, monkeypatch):
     """GPU twin of the emulator test of the same name: 256 identical crafted blocks through the lane mapping (every
     lane flushes in the same iteration; matches of every length 4..40 at offsets inside / just behind / far behind
     the LDS ring, periodic matches, literal runs of 0..80 bytes), known and unknown output size."""
     rng = np.random.default_rng(23)
     data = bytearray(rng.integers(0, 256, 7000, dtype=np.uint8).tobytes())
-    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 500, 4097, 6000):
+    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 200, 235, 236, 237, 238, 252, 253, 260, 500, 4097, 6000):
         for ml in list(range(4, 41)) + [64, 65, 100]:
             lit = int(rng.integers(0, 81)) if (off + ml) % 5 == 0 else int(rng.integers(0, 4))
             data += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
@@ -378,3 +378,38 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
         if w >= 0:
             assert np.array_equal(dst[i, :w], out[:w]), ("unknown", i)
         assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)
+
+
+def test_multi_device_host_batches(gpu, oracle):
+    """lz4hip_*_batch_host_multi (SURVEY.md 8b `deviceMask`, 8e): block i -> the (i mod N)-th selected device, results in
+    global order.  Always with mask 0x1; with two devices (and with mask 0 = all) when the box has them.  Every
+    block must be the oracle's bytes whichever device compressed it, and decode back to the input."""
+    from lz4net_amd import _lib
+    ndev = _lib.lib().lz4hip_device_count()
+    masks = [0x1, 0x0]
+    if ndev >= 2:
+        masks += [0x3, 0x2]
+    blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536), seeds=(5,))
+    blocks = blocks + [oracle.gen(2, 9, i, 1)[0] for i in range(37)]
+    want = [oracle.compress(a) for a in blocks]
+    want_hc = [oracle.compress(a, hc=True) for a in blocks]
+    for mask in masks:
+        for hc, ref in ((False, want), (True, want_hc)):
+            res, dst = gpu.encode(blocks, hc=hc, device_mask=mask)
+            for i, w in enumerate(ref):
+                assert res[i] == len(w) and np.array_equal(dst[i, :res[i]], w), (mask, hc, i)
+        used, back = gpu.decode(want, [a.size for a in blocks], known=True, device_mask=mask)
+        for i, a in enumerate(blocks):
+            assert used[i] == len(want[i]) and np.array_equal(back[i, :a.size], a), (mask, i)
+            assert (back[i, a.size:] == 0xA5).all()
+        produced, back = gpu.decode(want, [a.size + 3 for a in blocks], known=False, device_mask=mask)
+        for i, a in enumerate(blocks):
+            assert produced[i] == a.size and np.array_equal(back[i, :a.size], a), (mask, i)
+    # a mask that selects nothing visible is an argument error, not a silent fallback
+    import ctypes as C
+    src, sl = gpu.pack(want)
+    caps = np.array([a.size for a in blocks], np.int32)
+    dstb = np.zeros((len(want), 65536 + 64), np.uint8)
+    resb = np.zeros(len(want), np.int32)
+    b = gpu._batch(src, sl, dstb, caps, resb)
+    assert _lib.lib().lz4hip_decode_batch_host_multi(C.byref(b), 1, 1 << 63) == _lib.E_ARGUMENT

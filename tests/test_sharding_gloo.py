@@ -38,3 +38,53 @@ def test_two_rank_round_robin_gather():
             p.join(timeout=120)
             assert p.exitcode == 0
         assert got == [1000 + 3 * i for i in range(n_blocks)], n_blocks
+
+
+def _gpu_worker(rank, world, port, n_blocks, out):
+    """One rank of the real N>1 path: its round-robin share is generated, compressed and decompressed on ITS GPU
+    (rank % device_count: two ranks share the device on a 1-GPU box), only the 4-byte results are gathered."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(rank % torch.cuda.device_count())
+    from lz4net_amd import batch
+    cnt = batch.local_block_count(n_blocks, rank, world)
+    raw = batch.synth(2, 4242, rank, cnt, block_step=world)          # local block j == global block j*world + rank
+    comp = torch.empty((cnt, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, batch.BLOCK)
+    torch.cuda.synchronize()
+    ok = bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    sums = batch.checksum(back, batch.BLOCK)
+    got = batch.gather_results(clen, n_blocks)
+    got_sums = batch.gather_results((sums & 0x7FFFFFFF).to(torch.int32), n_blocks)
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if rank == 0:
+        out.put((got.tolist(), got_sums.tolist(), flags))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_the_codec_and_gather(oracle):
+    n_blocks = 131
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977) % 2000
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, n_blocks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    lens, sums, flags = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert flags == [True, True]
+    for i in range(n_blocks):                                        # global order, whichever rank did the work
+        block = oracle.gen(2, 4242, i, 1)[0]
+        assert lens[i] == len(oracle.compress(block)), i
+        assert sums[i] == (oracle.checksum(block) & 0x7FFFFFFF), i

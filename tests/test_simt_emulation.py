@@ -12,7 +12,10 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
-    return dict(chunked=int(m[7:])) if isinstance(m, str) else {}
+    if isinstance(m, str):
+        ring, _, stage = m[4:].partition("s")                        # "lane128s64": ring 128, staging 64
+        return dict(lane=int(ring), stage=int(stage or 64))
+    return {}
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
@@ -29,7 +32,7 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
 def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
@@ -50,7 +53,7 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -62,7 +65,7 @@ def test_decode_unknown_size(oracle, lane):
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, "chunked128", "chunked256"], ids=["wave-per-block", "chunked128", "chunked256"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
@@ -200,14 +203,15 @@ def test_encode_lane_many_blocks_per_lane(oracle):
 
 
 
-def test_chunked_decoder_lockstep_lanes_and_copy_lengths(oracle):
+@pytest.mark.parametrize("mapping", ["lane128s64", "lane128s128", "lane256s64", "lane256s128"])
+def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
     """64 identical blocks keep the 64 lanes of the lane-mapped decoder in lockstep, so every lane wants to flush in
     the same iteration (four rounds of the cooperative flush) -- on blocks built to contain matches of every length
     4..40 at offsets inside the ring, just behind it and far behind it (16- and 32-byte fetches), periodic matches and
     literal runs of 0..80 bytes."""
     rng = np.random.default_rng(23)
     data = bytearray(rng.integers(0, 256, 7000, dtype=np.uint8).tobytes())
-    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 500, 4097, 6000):
+    for off in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 60, 107, 108, 109, 110, 124, 125, 130, 200, 235, 236, 237, 238, 252, 253, 260, 500, 4097, 6000):
         for ml in list(range(4, 41)) + [64, 65, 100]:
             lit = int(rng.integers(0, 81)) if (off + ml) % 5 == 0 else int(rng.integers(0, 4))
             data += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
@@ -220,13 +224,13 @@ def test_chunked_decoder_lockstep_lanes_and_copy_lengths(oracle):
     comp = oracle.compress(block)
     for known in (True, False):
         comps = [np.concatenate([comp, np.zeros(1024, np.uint8)]) for _ in range(64)]
-        res, dst = emu.decode(comps, [block.size] * 64, known=known, src_lens=None if known else [len(comp)] * 64, chunked=128)
+        res, dst = emu.decode(comps, [block.size] * 64, known=known, src_lens=None if known else [len(comp)] * 64, **_mapping(mapping))
         for i in range(64):
             assert res[i] == (len(comp) if known else block.size), (known, i, res[i])
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
-@pytest.mark.parametrize("lane", [False, "chunked128"], ids=["wave-per-block", "chunked128"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
 def test_decode_arbitrary_streams(oracle, lane):
     """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
     them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching

@@ -1,4 +1,4 @@
-"""Decode rate of the wavefront mapping vs the chunked lane mapping for small batches (where is the crossover?)."""
+"""Decode rate of the wavefront mapping vs the lane mapping for small batches (where is the crossover?)."""
 import os, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ for dist in (2, 3):
     back = torch.empty_like(raw)
     for n in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
         row = []
-        for name in ("wave", "chunked"):
+        for name in ("wave", "lane"):
             os.environ["LZ4HIP_DECODER"] = name
             batch.decode(comp[:n], clen[:n], back[:n], batch.BLOCK)
             torch.cuda.synchronize()

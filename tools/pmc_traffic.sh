@@ -1,21 +1,49 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE of the decode kernels for the default bench workload (separate passes).
-tag=$1; dist=$2; blocks=$3; shift 3
-out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
-mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+# HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes as the MI355X guide prescribes) of the
+# three timed kernels of the default bench workload: decode (2^20 blocks), fast encode (2^20), LZ4HC (2^18).
+# Writes gpurun_out/pmc_traffic/pmc_traffic.json keyed on the hash of lz4net_amd/csrc (bench.py only quotes it when
+# the hash matches); copy it to profiles/r02/ to commit it.
+# Usage: bash tools/pmc_traffic.sh [dist] [blocks] [hc_blocks]
+dist=${1:-2}; blocks=${2:-1048576}; hcb=${3:-262144}
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 i=0
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  env "$@" timeout 300 rocprofv3 --pmc $pmc -d $out/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-extras --no-cpu --blocks $blocks --dist $dist > /dev/null 2>> $out/err.txt
+  timeout 600 rocprofv3 --pmc $pmc -d $out/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu --hc-only --blocks $blocks --hc-blocks $hcb --dist $dist > $out/bench_$i.json 2>> $out/err.txt
 done
 cd $GRAFT_REPO_ROOT
-python - $out $blocks <<'PY'
-import csv,glob,collections,json,sys
-out=sys.argv[1]; res=collections.defaultdict(float)
-for f in glob.glob(out+'/p*/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        if 'decode' in r['Kernel_Name']: res[r['Counter_Name']]+=float(r['Counter_Value'])
-d=dict(res); d['launches_summed']=2; d['blocks_per_launch']=int(sys.argv[2])
-json.dump(d, open(out+'/summary.json','w'), indent=1)
-print(out, json.dumps(d))
+python - $out $dist $blocks $hcb <<'PY'
+import csv, glob, json, sys, collections
+sys.path.insert(0, '.')
+import bench
+out, dist, blocks, hcb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+# per kernel family: the dispatches with the largest grid are the full-size launches; average their counters
+fam = {"decode": ("decode_lane_kernel", "decode_kernel"), "encode_fast": ("encode_fast_lane_kernel",), "encode_hc": ("encode_hc_lane_kernel",)}
+vals = {k: collections.defaultdict(list) for k in fam}
+for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    for k, names in fam.items():
+        mine = [r for r in rows if any(n in r['Kernel_Name'] for n in names)]
+        # per kernel instantiation: its full-size launches are those with its largest grid; a step of family k
+        # launches each instantiation once, so the family's traffic per step = sum of the per-instantiation means
+        by_name = collections.defaultdict(list)
+        for r in mine:
+            by_name[(r['Kernel_Name'], r['Counter_Name'])].append(r)
+        per_counter = collections.defaultdict(float)
+        for (name, counter), rs in by_name.items():
+            big = max(int(r['Grid_Size']) for r in rs)
+            full = [float(r['Counter_Value']) for r in rs if int(r['Grid_Size']) == big]
+            per_counter[counter] += sum(full) / len(full)
+        for c, v in per_counter.items():
+            vals[k][c].append(v)
+res = {"csrc_sha": bench.csrc_sha(), "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; bytes_per_launch = (FETCH + WRITE) * 1024, mean over the full-size launches; the guide's gfx950 caveat applies (FETCH_SIZE under-counts wide coalesced streaming reads by 2x; scattered widths uncalibrated)"}
+for k in fam:
+    v = vals[k]
+    if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        fe = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']); wr = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])
+        res[k] = {"dist": dist, "blocks": hcb if k == "encode_hc" else blocks, "fetch_bytes": int(fe * 1024), "write_bytes": int(wr * 1024),
+                  "bytes_per_launch": int((fe + wr) * 1024), "launches_averaged": len(v['FETCH_SIZE'])}
+json.dump(res, open(out + '/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res))
 PY
