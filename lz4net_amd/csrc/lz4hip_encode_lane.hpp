@@ -101,6 +101,19 @@ LZ4HIP_DEVICE int lane_count_equal(const uint8_t* __restrict__ in, int a, int b,
     return n;
 }
 
+// The same count when the caller already holds the 16 bytes at in[a] (`x0`, valid if `x0_ok`: a + 16 <= limit): a
+// search that measures many candidates against the same position loads its own side once.
+LZ4HIP_DEVICE int lane_count_equal_from(const uint8_t* __restrict__ in, int a, int b, int limit, const Vec16& x0, bool x0_ok)
+{
+    if (!x0_ok) return lane_count_equal(in, a, b, limit);
+    const Vec16 y = load_v16(in + b);
+    const uint64_t d0 = (x0.w[0] ^ y.w[0]) | ((uint64_t)(x0.w[1] ^ y.w[1]) << 32);
+    const uint64_t d1 = (x0.w[2] ^ y.w[2]) | ((uint64_t)(x0.w[3] ^ y.w[3]) << 32);
+    if (d0) return __builtin_ctzll(d0) >> 3;
+    if (d1) return 8 + (__builtin_ctzll(d1) >> 3);
+    return 16 + lane_count_equal(in, a + 16, b + 16, limit);
+}
+
 // exact copy of n bytes (literal runs)
 LZ4HIP_DEVICE void lane_copy(uint8_t* dst, const uint8_t* __restrict__ src, int n)
 {

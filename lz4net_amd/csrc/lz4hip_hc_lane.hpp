@@ -41,28 +41,37 @@ struct LaneHc {
     }
 
     // lz4hc.c:394-459
+    // (The chain walk is what the kernel spends its time in and each lane-level memory request costs the CU's
+    //  address unit a few cycles whatever it hits, so the walk makes as few as it can: the byte in[ip + ml] the
+    //  reference re-reads for every candidate lives in a register and is re-read only when ml changes, the first
+    //  16 bytes after in[ip + 4] are loaded once per search, and the next link is requested before the candidate is
+    //  looked at.)
     LZ4HIP_DEVICE int best_match(int ip, int matchlimit, int& match_at)
     {
         int attempts = kHcAttempts, ml = 0, repl = 0, delta = 0;
         insert_upto(ip);
         const uint32_t word = load_u32(in + ip);
+        const bool fwd_ok = ip + 4 + 16 <= matchlimit;
+        const Vec16 fwd = fwd_ok ? load_v16(in + ip + 4) : Vec16{ { 0, 0, 0, 0 } };
         int ref = (int)head[hash15(word)];
         if (ref >= ip - 4) {                                           // lz4hc.c:411-421
             if (load_u32(in + ref) == word) {
                 delta = (ip - ref) & 0xFFFF;
-                repl = ml = lane_count_equal(in, ip + 4, ref + 4, matchlimit) + 4;
+                repl = ml = lane_count_equal_from(in, ip + 4, ref + 4, matchlimit, fwd, fwd_ok) + 4;
                 match_at = ref;
             }
             ref -= (int)chain[ref & 0xFFFF];
         }
+        uint32_t probe_byte = in[ip + ml];                             // *(ip+ml), lz4hc.c:427
         while (ref >= ip - kMaxDistance && attempts > 0) {             // lz4hc.c:424-434
             attempts--;
             if (ref < 0) break;                                        // cannot happen on the reference's flows
-            if (in[ref + ml] == in[ip + ml] && load_u32(in + ref) == word) {
-                const int cand = lane_count_equal(in, ip + 4, ref + 4, matchlimit) + 4;
-                if (cand > ml) { ml = cand; match_at = ref; }
+            const int link = (int)chain[ref & 0xFFFF];
+            if (in[ref + ml] == probe_byte && load_u32(in + ref) == word) {
+                const int cand = lane_count_equal_from(in, ip + 4, ref + 4, matchlimit, fwd, fwd_ok) + 4;
+                if (cand > ml) { ml = cand; match_at = ref; probe_byte = in[ip + ml]; }
             }
-            ref -= (int)chain[ref & 0xFFFF];
+            ref -= link;
         }
         if (repl) {                                                    // lz4hc.c:437-455
             int q = ip;
@@ -85,17 +94,21 @@ struct LaneHc {
         const int back = ip - start_limit;
         insert_upto(ip);
         const uint32_t word = load_u32(in + ip);
+        const bool fwd_ok = ip + 4 + 16 <= matchlimit;
+        const Vec16 fwd = fwd_ok ? load_v16(in + ip + 4) : Vec16{ { 0, 0, 0, 0 } };
         int ref = (int)head[hash15(word)];
+        uint32_t probe_byte = in[start_limit + longest];               // *(startLimit + longest), lz4hc.c:480
         while (ref >= ip - kMaxDistance && attempts > 0) {
             attempts--;
             if (ref < 0) break;
-            if (in[start_limit + longest] == in[ref - back + longest] && load_u32(in + ref) == word) {
-                const int fwd_end = ip + 4 + lane_count_equal(in, ip + 4, ref + 4, matchlimit);
+            const int link = (int)chain[ref & 0xFFFF];
+            if (in[ref - back + longest] == probe_byte && load_u32(in + ref) == word) {
+                const int fwd_end = ip + 4 + lane_count_equal_from(in, ip + 4, ref + 4, matchlimit, fwd, fwd_ok);
                 int s = ip, r = ref;
                 while (s > start_limit && r > 0 && in[s - 1] == in[r - 1]) { s--; r--; }   // lz4hc.c:505
-                if (fwd_end - s > longest) { longest = fwd_end - s; match_at = r; start_at = s; }
+                if (fwd_end - s > longest) { longest = fwd_end - s; match_at = r; start_at = s; probe_byte = in[start_limit + longest]; }
             }
-            ref -= (int)chain[ref & 0xFFFF];
+            ref -= link;
         }
         return longest;
     }
