@@ -361,13 +361,14 @@ HostContext* host_context(int dev)
     return ctx[dev];
 }
 
-// f(i) for i in [0, n): on the calling thread for small jobs, on up to 8 threads for large ones (row gathers and
+// f(i) for i in [0, n): on the calling thread for small jobs, on up to 16 threads (LZ4HIP_HOST_THREADS) for large ones (row gathers and
 // scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
 template <class F>
 void for_rows(int64_t n, size_t bytes, F f)
 {
     unsigned t = std::thread::hardware_concurrency();
-    t = t > 8 ? 8 : t;
+    static const unsigned cap = [] { const char* e = getenv("LZ4HIP_HOST_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
+    t = t > cap ? cap : t;
     if (bytes < (8u << 20) || n < 2 || t < 2) { for (int64_t i = 0; i < n; i++) f(i); return; }
     if ((int64_t)t > n) t = (unsigned)n;
     std::vector<std::thread> pool;
