@@ -80,6 +80,83 @@ LZ4HIP_DEVICE int put_length_bytes(uint8_t* out, int rest)
     return n255 + 1;
 }
 
+// Sum of the skip schedule's steps over attempts [0, a): step(t) = t >> 6 (lz4.c:645, skipStrength 6).
+LZ4HIP_DEVICE int skip_sum(int a) { const int q = a >> 6, r = a & 63; return 32 * q * (q - 1) + q * r; }
+
+// The match search of one sequence (lz4.c:642-654), 64 probes per step.  The probe positions of a search are a fixed
+// arithmetic function of the probe count (attempts start at 67, step = attempts >> 6), so lane i takes the i-th next
+// probe: it loads its 4 bytes, hashes them, gathers its table entry and the 4 bytes at that candidate; the first lane
+// whose candidate matches (or whose successor would leave the input, lz4.c:648) ends the search.
+// What makes the serial loop serial is that probe i sees the table writes of the probes before it -- which only matters
+// where probes of one step share a bucket.  Those are found exactly: every probing lane writes its LANE NUMBER to its
+// bucket and reads it back; a lane that reads another number shares its bucket, and one ballot per such bucket
+// (lanes with that hash) gives the bucket's lanes as a mask.  Inside a bucket the candidate of a lane is the position
+// of the next lower lane (its word comes over the lane crossbar, no memory access), the lowest lane keeps the gathered
+// table entry.  Then the buckets get back their old entries, and of the lanes up to the winner the highest one of each
+// bucket writes its position -- the table ends up exactly as the serial loop leaves it.
+// In: ip = first probe position.  Out (true): ip = match position, ref = candidate.  False: ran out of input.
+template <bool GENERIC>
+LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit)
+{
+    typedef FastTable<GENERIC> T;
+    typedef typename T::entry entry;
+    const int lane = wv::lane();
+    const uint64_t below_me = (1ull << lane) - 1ull;
+    int attempts = 67;
+    for (;;) {
+        const int a = attempts + lane;
+        const int p = ip + skip_sum(a) - skip_sum(attempts);
+        const int p_next = p + (a >> 6);
+        const bool valid = p_next <= mflimit;                        // (monotonic: the probing lanes are a prefix)
+        uint32_t w = 0;
+        if (valid) w = load_u32(in + p);
+        const uint32_t h = T::hash(w);
+        int r = 0;
+        if (valid) r = (int)table[h];
+        uint32_t rw = 0;                                             // the candidate's bytes, for lanes alone in their bucket
+        if (valid) rw = load_u32(in + r);
+        wv::mem_sync();
+        if (valid) table[h] = (entry)lane;
+        wv::mem_sync();
+        uint64_t shared = wv::ballot(valid && (int)table[h] != lane);
+        wv::mem_sync();
+        uint64_t bucket = 0;                                         // the lanes of this lane's bucket (0: alone)
+        while (shared) {                                             // rare: one round per shared bucket
+            const uint32_t hb = wv::readlane(h, wv::ctz64(shared));
+            const uint64_t g = wv::ballot(valid && h == hb);
+            if (valid && h == hb) bucket = g;
+            shared &= ~g;
+        }
+        const uint64_t lower = bucket & below_me;
+        const int prev = lower ? 63 - __builtin_clzll(lower) : lane;
+        const uint32_t pw = wv::shuffle(w, prev);
+        const int pp = (int)wv::shuffle((uint32_t)p, prev);
+        const int cref = lower ? pp : r;
+        const bool cand = valid && (!GENERIC || cref >= p - kMaxDistance) && (lower ? pw : rw) == w;   // lz4.c:427 / :654
+        const uint64_t stop = wv::ballot(cand || !valid);
+        const int m = stop ? wv::ctz64(stop) : 63;                   // the last lane of this step that probes (if valid)
+        // table: lanes after the winner restore their bucket, of the others the highest lane of each bucket writes
+        if (wv::any(bucket != 0)) {
+            if (valid) table[h] = (entry)r;                          // (lanes of one bucket hold the same old entry)
+            wv::mem_sync();
+            const uint64_t upto_m = m >= 63 ? ~0ull : ((2ull << m) - 1ull);
+            const uint64_t higher = bucket & ~below_me & ~(1ull << lane) & upto_m;
+            if (valid && lane <= m && higher == 0) table[h] = (entry)p;
+        } else if (valid) {
+            table[h] = (entry)(lane <= m ? p : r);
+        }
+        wv::mem_sync();
+        if (stop) {
+            if (!wv::readlane((uint32_t)valid, m)) return false;
+            ip = (int)wv::readlane((uint32_t)p, m);
+            ref = (int)wv::readlane((uint32_t)cref, m);
+            return true;
+        }
+        ip = (int)wv::readlane((uint32_t)p_next, 63);                // 64 probes without a match
+        attempts += 64;
+    }
+}
+
 template <bool GENERIC>
 LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int cap, unsigned char* table_bytes)
 {
@@ -103,26 +180,11 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
             if (lane == 0) table[h0] = 0;
         }
         ip = 1;                                                       // lz4.c:631: position 0 is never probed
-        uint32_t fwd_word = input_word(in, ip);
         for (;;) {
-            // ---- find a match: lz4.c:642-654 ----
-            int attempts = 67, probe = ip, ref;
+            // ---- find a match: lz4.c:642-654, 64 probes of the skip schedule per step ----
+            int ref = 0;
             uint32_t cur_word;
-            bool out_of_input = false;
-            for (;;) {
-                cur_word = fwd_word;
-                const uint32_t h = T::hash(cur_word);
-                const int step = attempts++ >> 6;
-                ip = probe;
-                probe = ip + step;
-                if (probe > mflimit) { out_of_input = true; break; }
-                fwd_word = input_word(in, probe);
-                ref = (int)wv::uniform((uint32_t)table[h]);
-                if (lane == 0) table[h] = (entry)ip;
-                if (GENERIC && ref < ip - kMaxDistance) continue;     // lz4.c:427
-                if (input_word(in, ref) == cur_word) break;
-            }
-            if (out_of_input) break;
+            if (!wave_find_match<GENERIC>(in, table, ip, ref, mflimit)) break;
 
             // ---- catch up: lz4.c:657 ----
             {
@@ -175,7 +237,6 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
                 token = 0;
             }
             anchor = ip++;                                            // lz4.c:754-755
-            fwd_word = input_word(in, ip);
         }
     }
 tail:

@@ -5,7 +5,7 @@ import torch
 from lz4net_amd import batch
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
-for dist in (2, 3, 1):
+for dist in (2, 3, 1, 0):
     raw = batch.synth(dist, 7, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
     batch.encode(raw[:4096], batch.BLOCK, comp[:4096], batch.BOUND)
