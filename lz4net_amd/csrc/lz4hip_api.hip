@@ -37,6 +37,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // A lone wavefront of the lane mapping needs milliseconds for its 64 blocks, so the mapping only pays once the
 // batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
+constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 
 int fail(int code, const std::string& what)
@@ -161,46 +162,51 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
     if (mode == LZ4HIP_MODE_FAST) {
-        // Two mappings (lz4hip_encode.hpp: one wavefront per block, table in LDS; lz4hip_encode_lane.hpp:
-        // one lane per block, tables in a global slab).  Batches large enough to fill the lanes use the
-        // latter.  LZ4HIP_ENCODER=wave|lane overrides (A-B runs).
+        // Two mappings (lz4hip_encode.hpp: one wavefront per block, table in LDS, 64 probes of the match search per
+        // step; lz4hip_encode_lane.hpp: one lane per block, tables in a global slab).  The first is several times
+        // faster where matches are far between (incompressible data: 6x), the second where sequences are short (a
+        // chain of dependent steps per sequence: 64 chains per wavefront instead of one).  A batch large enough to
+        // fill the lanes is therefore encoded by two launches: the wavefront mapping over every block, which hands a
+        // block over (kDeferredResult) as soon as 16 consecutive sequences cover less than 1 KiB, then the lane mapping
+        // over the blocks handed over.  Small batches use the wavefront mapping only.
+        // LZ4HIP_ENCODER=wave|lane forces ONE mapping for every block (tests, A-B runs).
         const char* force = getenv("LZ4HIP_ENCODER");
-        // 'l' (default for large batches): one lane per block; 'w': one wavefront per block.
-        char pick = d.n_blocks >= 16384 ? 'l' : 'w';
+        char pick = d.n_blocks >= kLaneEncodeMinBlocks ? 'a' : 'w';  // 'a': both launches
         if (force && (force[0] == 'w' || force[0] == 'l')) pick = force[0];
+        Lease lease;
+        void* ws = nullptr;
+        int64_t groups = 0;
         if (pick != 'w') {
             int dev = 0, cus = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             int wpc = kLaneEncodeWavesPerCu;
             if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
-            Lease lease;
             int rc = lease_begin(g_fast_ws, stream, lease);
             if (rc) return rc;
             // the slab holds one table per resident lane; if it cannot be had, halve the residency, and
             // in the end fall back to the wavefront mapping (which needs no workspace)
-            void* ws = nullptr;
-            int64_t groups = 0;
             for (; wpc >= 1; wpc /= 2) {
                 groups = (int64_t)cus * wpc;
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
                 if (lease_reserve(lease, (size_t)groups * 64 * (size_t)kLaneTableBytes + 256) == 0) { ws = lease.p; break; }
             }
-            if (ws) {
-                HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                                   (unsigned long long*)ws, (uint8_t*)ws + 256);
-                HIP_TRY(hipGetLastError());
-                count_dispatch(LZ4HIP_K_ENCODE_LANE);
-                if ((rc = lease_end(lease, stream))) return rc;
-            } else {
-                lease.lock.unlock();
-                pick = 'w';
-            }
+            if (!ws) { lease.lock.unlock(); pick = 'w'; }
         }
-        if (pick == 'w') {
-            hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, 0);
+        if (pick != 'l') {
+            hipLaunchKernelGGL(encode_fast_kernel, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d,
+                               pick == 'a' ? (int)kEncodeMayDefer : 0);
+            HIP_TRY(hipGetLastError());
             count_dispatch(LZ4HIP_K_ENCODE_WAVE);
+        }
+        if (pick != 'w') {
+            HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+            hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                               (unsigned long long*)ws, (uint8_t*)ws + 256, pick == 'a' ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            count_dispatch(LZ4HIP_K_ENCODE_LANE);
+            int rc = lease_end(lease, stream);
+            if (rc) return rc;
         }
     } else if (mode == LZ4HIP_MODE_HC) {
         int dev = 0, cus = 0;

@@ -23,6 +23,12 @@ constexpr uint32_t kGolden = 2654435761u;
 constexpr int kHcAttempts = 256;        // MAX_NB_ATTEMPTS (original/lz4hc.c:184)
 constexpr int kHcOptimalMl = 18;        // OPTIMAL_ML (original/lz4hc.c:194)
 constexpr int kFastTableBytes = 16384;  // u16[8192] (64k variant) or u32[4096] (generic variant)
+// Fast encode of a large batch runs two launches: one wavefront per block first (lz4hip_encode.hpp), which hands a
+// block whose sequences come thick and fast over to the lane-per-block launch by leaving this value in result[]
+// (never a valid return value: sizes are >= 0, error codes > INT32_MIN).
+constexpr int32_t kDeferredResult = INT32_MIN;
+constexpr int kDeferCheckSequences = 16;   // every 16 sequences ...
+constexpr int kDeferBytesPerSequence = 64;  // ... the block is handed over if they covered less than 16 x 64 input bytes
 
 // One batch of independent blocks, device-resident.  Block i lives at base + (off ? off[i] : i*stride).
 struct Batch {

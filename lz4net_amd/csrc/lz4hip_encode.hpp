@@ -158,7 +158,7 @@ LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC
 }
 
 template <bool GENERIC>
-LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int cap, unsigned char* table_bytes)
+LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int cap, unsigned char* table_bytes, bool may_defer = false)
 {
     typedef FastTable<GENERIC> T;
     typedef typename T::entry entry;
@@ -166,6 +166,7 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
     const int lane = wv::lane();
     const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
     int ip = 0, anchor = 0, op = 0;
+    int sequences = 0, checked_at = 0;                                // (hand-over rule, see kDeferredResult)
 
     if (n >= kMinLength) {                                            // lz4.c:615
         // fresh zeroed table per block (lz4.c:583 / `new ushort[8192]`, Unsafe.cs:283)
@@ -220,6 +221,12 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
                 if (lane == 0) out[token_at] = (uint8_t)token;
                 if (extra >= 15) op += put_length_bytes(out + op, extra - 15);
 
+                // A block made of short sequences is a chain of dependent steps that 64 lanes cannot shorten; the
+                // lane-per-block launch runs 64 such chains per wavefront.  Nothing of this block is final yet.
+                if (may_defer && (++sequences % kDeferCheckSequences) == 0) {
+                    if (ip - checked_at < kDeferCheckSequences * kDeferBytesPerSequence) return kDeferredResult;
+                    checked_at = ip;
+                }
                 if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
                 // ---- re-seed the table and test the next position: lz4.c:739-751 ----
                 {
@@ -254,9 +261,12 @@ tail:
 
 // One wavefront (= one workgroup of 64 threads) per block; 16 KiB of dynamic LDS per workgroup,
 // so up to 10 blocks are resident per CU.
-// only_generic != 0: handle just the blocks of LZ4_64KLIMIT bytes and more.
-__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int only_generic)
+// flags: kEncodeOnlyGeneric: handle just the blocks of LZ4_64KLIMIT bytes and more; kEncodeMayDefer: blocks below
+// LZ4_64KLIMIT made of short sequences get kDeferredResult instead of being finished (a second launch takes them).
+enum EncodeKernelFlags { kEncodeOnlyGeneric = 1, kEncodeMayDefer = 2 };
+__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int flags)
 {
+    const int only_generic = flags & kEncodeOnlyGeneric;
     LZ4HIP_DYN_LDS(lds);
     const int64_t blk = (int64_t)blockIdx.x;
     if (blk >= b.n_blocks) return;
@@ -266,7 +276,7 @@ __global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int only_gener
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);
     int r;
-    if (n < k64kLimit) r = encode_fast_block<false>(src, n, dst, cap, lds);      // lz4.c:783-785
+    if (n < k64kLimit) r = encode_fast_block<false>(src, n, dst, cap, lds, (flags & kEncodeMayDefer) != 0);      // lz4.c:783-785
     else               r = encode_fast_block<true>(src, n, dst, cap, lds);
     if (wv::lane() == 0) b.result[blk] = r;
 }

@@ -246,13 +246,15 @@ tail:
 
 // Persistent grid: every lane pulls block indices from `counter` until the batch is exhausted.
 // `tables` holds kLaneTableBytes of hash table per lane of the grid.
-__global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables)
+// only_deferred != 0: just the blocks the wavefront-per-block launch handed over (result[] == kDeferredResult).
+__global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables, int only_deferred)
 {
     uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLaneTableBytes;
     int epoch = 63;                                                   // the slab's contents are unknown at launch
     for (;;) {
         const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
         if (blk >= b.n_blocks) return;
+        if (only_deferred && b.result[blk] != kDeferredResult) continue;
         const int n = batch_src_len(b, blk), cap = batch_dst_cap(b, blk);
         const uint8_t* src = batch_src(b, blk);
         uint8_t* dst = batch_dst(b, blk);

@@ -73,6 +73,22 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
     return res, dst
 
 
+def encode_two_launches(blocks, caps=None):
+    """launch_encode's default for large batches: wavefront-per-block launch with the hand-over rule, then the lane-per-block
+    launch over the blocks handed over.  Returns (result, dst, deferred flags)."""
+    src, sl = pack(blocks)
+    if caps is None:
+        caps = [len(b) + len(b) // 255 + 16 for b in blocks]
+    caps = np.array(caps, np.int32)
+    ds = max(int(caps.max()), 1) + 64
+    dst = np.full((len(blocks), ds), 0xA5, np.uint8)
+    res = np.zeros(len(blocks), np.int32)
+    deferred = np.zeros(len(blocks), np.int32)
+    lib().emu_encode_fast_two_launches(_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res),
+                                       C.c_int64(len(blocks)), _p(deferred))
+    return res, dst, deferred
+
+
 def synth(dist, seed, first_block, n, length, stride=None, block_step=1):
     stride = length if stride is None else stride
     out = np.zeros((n, max(stride, 1)), np.uint8)

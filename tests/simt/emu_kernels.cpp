@@ -91,7 +91,23 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* tables = ws.data() + 256;
-    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables); });
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables, 0); });
+}
+
+// The two launches of a large batch (launch_encode, 'a'): one wavefront per block with the hand-over rule, then one lane
+// per block over the blocks handed over.  `deferred` receives 1 for every block the first launch handed over.
+void emu_encode_fast_two_launches(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                                  int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int32_t* deferred)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, kEncodeMayDefer); });
+    for (int64_t i = 0; i < n; i++) deferred[i] = result[i] == kDeferredResult;
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)64 * kLaneTableBytes, 0x5A);
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* tables = ws.data() + 256;
+    simt::launch(dim3(1), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables, 1); });
 }
 
 #ifdef LZ4HIP_HAVE_HC

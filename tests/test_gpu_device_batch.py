@@ -155,6 +155,34 @@ def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
         assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
 
 
+def test_fast_encode_default_dispatch_two_launches(torch_cuda, oracle):
+    """Default dispatch of a large fast-encode batch: the wavefront mapping runs over every block and hands the blocks made
+    of short sequences over to the lane mapping.  A batch mixing incompressible, fuzzer-style, record-like and zero blocks
+    must launch BOTH kernels, leave no block with the hand-over marker, and produce the reference's bytes for every block
+    sampled, whichever kernel finished it."""
+    torch = torch_cuda
+    from lz4net_amd import _lib, batch
+    per = 8192
+    parts = [batch.synth(d, 4242, 0, per) for d in (1, 2, 3, 0)]
+    raw = torch.cat(parts, dim=0)
+    n = raw.shape[0]
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    before = _lib.dispatch_counts()
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    after = _lib.dispatch_counts()
+    assert after[2] > before[2] and after[3] > before[3], "both fast-encode mappings must have been launched"
+    assert bool((clen > 0).all()), "a block was left with the hand-over marker (or failed)"
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, batch.BLOCK)
+    assert bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    lens = clen.cpu().numpy()
+    for k, d in enumerate((1, 2, 3, 0)):
+        for j in (0, 1, per // 2, per - 1):
+            i = k * per + j
+            want = oracle.compress(oracle.gen(d, 4242, j, 1)[0])
+            assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), (d, j)
+
+
 @pytest.mark.parametrize("decoder", ["wave", "lane"])
 def test_decode_into_unaligned_rows(torch_cuda, oracle, decoder):
     """Destination rows at odd addresses and an odd stride, sources at odd addresses too: the 16-byte stores of both

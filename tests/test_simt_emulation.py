@@ -120,6 +120,34 @@ def test_encode_fast_limited_output(oracle, lane):
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
+def test_encode_fast_two_launches_hand_over(oracle):
+    """Default dispatch of a large batch: the wavefront mapping hands blocks made of short sequences over to the lane
+    mapping (kDeferredResult) and finishes the others; every block ends up with the reference's bytes whoever encoded it."""
+    blocks = _blocks(oracle, sizes=(0, 13, 300, 4096, 20000, 65536, 65547))
+    half = oracle.gen(1, 9, 0, 1, 65536)[0].copy()          # incompressible start, dense matches later: handed over late
+    half[40000:] = oracle.gen(2, 9, 0, 1, 65536)[0][:25536]
+    blocks.append(half)
+    res, dst, deferred = emu.encode_two_launches(blocks)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+    # incompressible blocks stay with the wavefront mapping, fuzzer-style blocks of some length are handed over
+    kinds = {}
+    for i, a in enumerate(blocks):
+        kinds.setdefault(bool(deferred[i]), []).append(a.size)
+    assert True in kinds and False in kinds, kinds
+    assert deferred[-1] == 1
+    # limited output through both launches
+    lens = [len(oracle.compress(a)) for a in blocks]
+    for delta in (0, -1):
+        caps = [max(l + delta, 0) for l in lens]
+        res, dst, _ = emu.encode_two_launches(blocks, caps=caps)
+        for i, a in enumerate(blocks):
+            assert res[i] == oracle.compress_raw(a, caps[i])[0], (i, delta)
+            assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
+
+
 def test_synth_generators_match_cpu_twins(oracle):
     for dist in range(4):
         for length in (1, 100, 4096, 65536):
