@@ -330,19 +330,26 @@ struct Pinned {
     ~Pinned() { /* see ~Scratch */ }
 };
 
-// Per calling thread: the two copy streams and the events of the three-stage host pipeline (H2D | kernels | D2H).
+// Per calling thread and device: the streams and events of the host pipeline (H2D | kernels | D2H).  A slice owns one of
+// kHostSlots slots (pinned in/out images, device in/out images, a kernel stream): the kernels of consecutive slices run
+// on DIFFERENT streams, so that a slice's kernels start as soon as its input has landed, next to those of the slices
+// before it -- a launch over a thousand blocks cannot fill the device and takes the same few milliseconds as one over
+// four thousand.
+constexpr int kHostSlots = 4;
 struct HostPipe {
     bool ready = false;
     int dev = -1;                // streams and events belong to a device: one set per (thread, device)
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t e_in[2], e_k[2], e_out[2];
+    hipStream_t s_in = nullptr, s_out = nullptr, s_k[kHostSlots];
+    hipEvent_t e_in[kHostSlots], e_k[kHostSlots], e_out[kHostSlots], e_start;
     int init()
     {
         if (ready) return 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&e_start, hipEventDisableTiming));
+        for (int k = 0; k < kHostSlots; k++) {
+            HIP_TRY(hipStreamCreateWithFlags(&s_k[k], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&e_in[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&e_k[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&e_out[k], hipEventDisableTiming));
@@ -356,7 +363,7 @@ struct HostPipe {
 // (and the multi-device entry points run one worker thread per device).
 struct HostContext {
     Scratch scratch;
-    Pinned pin_in[2], pin_out[2];
+    Pinned pin_in[kHostSlots], pin_out[kHostSlots];
     HostPipe pipe;
 };
 HostContext* host_context(int dev)
@@ -386,11 +393,11 @@ void for_rows(int64_t n, size_t bytes, F f)
 }
 
 // Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
-// The batch is cut into slices (64 MiB .. 1 GiB); per slice: rows are gathered into pinned memory (host threads), ONE
-// host-to-device copy, the kernels, ONE device-to-host copy into pinned memory, rows scattered to the caller.
-// Three streams (copy in | the calling thread's stream for the kernels | copy out) and two sets of buffers: while the
-// kernels of slice k run, slice k+1 is on its way in, slice k-1 on its way out (PCIe is full duplex), and the host
-// gathers / scatters the slices next to those.
+// The batch is cut into slices; per slice: rows are gathered into pinned memory (host threads), ONE host-to-device copy,
+// the kernels, ONE device-to-host copy into pinned memory, rows scattered to the caller.  Copies in, kernels and copies
+// out run on their own streams over kHostSlots sets of buffers: slice k+1 travels in and slice k-1 out while slice k is
+// being processed (PCIe is full duplex), kernels of neighbouring slices overlap, and the host gathers / scatters next to
+// all that.
 template <class Run>
 int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 {
@@ -410,16 +417,18 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
         max_dst = dc > max_dst ? dc : max_dst;
     }
     const size_t s_stride = align_up((size_t)max_src + 16, 16), d_stride = align_up((size_t)max_dst + 16, 16);
-    // slice size: a small batch goes in one piece; a large one in >= 3 slices (so that copies, kernels and the host's
-    // gather/scatter overlap) of 64 MiB .. 1 GiB -- a kernel over fewer than ~1000 blocks costs the same few
-    // milliseconds whatever its size, so slices should not be smaller than they have to be
+    // slice size: a small batch goes in one piece; a large one in about 6 slices (LZ4HIP_HOST_SLICES; profiles/r02/host_slices_sweep.txt) of 32 MiB .. 512 MiB
+    // of rows each
     const size_t row_bytes = s_stride + d_stride;
-    int64_t per_slice = (n + 2) / 3;
-    const int64_t lo = (int64_t)((64u << 20) / row_bytes), hi = (int64_t)((1024u << 20) / row_bytes);
+    static const int want_slices = [] { const char* e = getenv("LZ4HIP_HOST_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 6; }();
+    int64_t per_slice = (n + want_slices - 1) / want_slices;
+    const int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
     per_slice = per_slice < lo ? lo : per_slice;
     per_slice = per_slice > hi ? hi : per_slice;
     per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
     const size_t m = (size_t)per_slice;
+    const int64_t n_slices = (n + per_slice - 1) / per_slice;
+    const int slots = n_slices < kHostSlots ? (int)n_slices : kHostSlots;
     // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
     const size_t in_lens = align_up(s_stride * m, 256), in_caps = in_lens + align_up(4 * m, 256), in_bytes = in_caps + align_up(4 * m, 256);
     const size_t out_res = align_up(d_stride * m, 256), out_bytes = out_res + align_up(4 * m, 256);
@@ -430,16 +439,19 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     Scratch& g_scratch = hc->scratch;
     Pinned* g_pin_in = hc->pin_in;
     Pinned* g_pin_out = hc->pin_out;
-    if ((rc = g_scratch.reserve(2 * (in_bytes + out_bytes)))) return rc;
-    for (int k = 0; k < 2; k++) {
+    if ((rc = g_scratch.reserve((size_t)slots * (in_bytes + out_bytes)))) return rc;
+    for (int k = 0; k < slots; k++) {
         if ((rc = g_pin_in[k].reserve(in_bytes))) return rc;
         if ((rc = g_pin_out[k].reserve(out_bytes))) return rc;
     }
     if ((rc = hc->pipe.init())) return rc;
     HostPipe& pp = hc->pipe;
-    uint8_t* d_in[2] = { (uint8_t*)g_scratch.p, (uint8_t*)g_scratch.p + in_bytes };
-    uint8_t* d_out[2] = { d_in[1] + in_bytes, d_in[1] + in_bytes + out_bytes };
-    hipStream_t stream = hipStreamPerThread;                         // kernels (and whatever the caller queued before)
+    uint8_t* d_in[kHostSlots];
+    uint8_t* d_out[kHostSlots];
+    for (int k = 0; k < slots; k++) {
+        d_in[k] = (uint8_t*)g_scratch.p + (size_t)k * (in_bytes + out_bytes);
+        d_out[k] = d_in[k] + in_bytes;
+    }
 
     auto src_row = [&](int64_t i) { return (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride); };
     auto dst_row = [&](int64_t i) { return (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride); };
@@ -463,15 +475,25 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 #define PIPE_TRY(expr) do { if ((expr) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, #expr " failed"); } } while (0)
 
     int err = 0;
-    int64_t prev_first = 0, prev_cnt = 0;
-    int slice = 0;
-    // earlier work of this thread on its stream may still use the device buffers of a previous call
-    PIPE_TRY(hipEventRecord(pp.e_k[0], stream));
-    PIPE_TRY(hipEventRecord(pp.e_k[1], stream));
+    int64_t drained = 0;                                             // slices [0, drained) are back in the caller's buffers
+    auto drain_one = [&]() {                                         // (blocking)
+        const int slot = (int)(drained % slots);
+        PIPE_TRY(hipEventSynchronize(pp.e_out[slot]));
+        if (!err) {
+            const int64_t first = drained * per_slice;
+            scatter(first, n - first < per_slice ? n - first : per_slice, slot);
+        }
+        drained++;
+    };
+    // whatever the caller queued on its stream before this call comes first
+    PIPE_TRY(hipEventRecord(pp.e_start, hipStreamPerThread));
+    PIPE_TRY(hipStreamWaitEvent(pp.s_in, pp.e_start, 0));
+    int64_t slice = 0;
     for (int64_t first = 0; first < n && !err; first += per_slice, slice++) {
         const int64_t cnt = n - first < per_slice ? n - first : per_slice;
-        const int slot = slice & 1;
-        // (pinned slot: its H2D finished before kernel k-2 did, and its scatter ran synchronously two iterations ago)
+        const int slot = (int)(slice % slots);
+        while (!err && drained + slots <= slice) drain_one();        // the slot's previous slice must be out of its buffers
+        if (err) break;
         uint8_t* pi = (uint8_t*)g_pin_in[slot].p;
         int32_t* lens = (int32_t*)(pi + in_lens);
         int32_t* caps = (int32_t*)(pi + in_caps);
@@ -480,39 +502,33 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
             const int32_t sl = src_len(first + j);
             if (sl > 0) memcpy(pi + s_stride * (size_t)j, src_row(first + j), (size_t)sl);
         });
-        // copy in: after the kernels that last read this device slot (slice k-2)
-        PIPE_TRY(hipStreamWaitEvent(pp.s_in, pp.e_k[slot], 0));
+        // copy in (the slot's previous kernels have finished: their slice has been drained)
         PIPE_TRY(hipMemcpyAsync(d_in[slot], pi, in_bytes, hipMemcpyHostToDevice, pp.s_in));
         PIPE_TRY(hipEventRecord(pp.e_in[slot], pp.s_in));
-        // kernels: after their input has landed and the copy-out of slice k-2 has left this output slot
-        PIPE_TRY(hipStreamWaitEvent(stream, pp.e_in[slot], 0));
-        if (slice >= 2) PIPE_TRY(hipStreamWaitEvent(stream, pp.e_out[slot], 0));
+        // kernels, on the slot's own stream: after their input has landed
+        hipStream_t ks = pp.s_k[slot];
+        PIPE_TRY(hipStreamWaitEvent(ks, pp.e_in[slot], 0));
         if (err) break;
         lz4hip_batch_t db;
         db.src = d_in[slot]; db.src_off = nullptr; db.src_stride = (int64_t)s_stride; db.src_len = (const int32_t*)(d_in[slot] + in_lens);
         db.dst = d_out[slot]; db.dst_off = nullptr; db.dst_stride = (int64_t)d_stride; db.dst_cap = (const int32_t*)(d_in[slot] + in_caps);
         db.dst_cap_all = 0; db.src_len_all = (int32_t)max_src;   /* upper-bound hint */ db.result = (int32_t*)(d_out[slot] + out_res); db.n_blocks = cnt;
-        if ((err = run(&db, stream))) break;
-        PIPE_TRY(hipEventRecord(pp.e_k[slot], stream));
+        if ((err = run(&db, ks))) break;
+        PIPE_TRY(hipEventRecord(pp.e_k[slot], ks));
         // copy out: after the kernels
         PIPE_TRY(hipStreamWaitEvent(pp.s_out, pp.e_k[slot], 0));
         PIPE_TRY(hipMemcpyAsync(g_pin_out[slot].p, d_out[slot], out_bytes, hipMemcpyDeviceToHost, pp.s_out));
         PIPE_TRY(hipEventRecord(pp.e_out[slot], pp.s_out));
         if (err) break;
-        if (prev_cnt) {                                              // drain the previous slice while this one is in flight
-            PIPE_TRY(hipEventSynchronize(pp.e_out[slot ^ 1]));
-            if (err) break;
-            scatter(prev_first, prev_cnt, slot ^ 1);
-        }
-        prev_first = first; prev_cnt = cnt;
+        // slices that have already arrived are scattered while the later ones are in flight
+        while (!err && drained < slice && hipEventQuery(pp.e_out[drained % slots]) == hipSuccess) drain_one();
     }
-    if (!err && prev_cnt) {
-        const int slot = (slice - 1) & 1;
-        PIPE_TRY(hipEventSynchronize(pp.e_out[slot]));
-        if (!err) scatter(prev_first, prev_cnt, slot);
-    }
+    while (!err && drained < slice) drain_one();
 #undef PIPE_TRY
-    if (err) { (void)hipStreamSynchronize(pp.s_in); (void)hipStreamSynchronize(stream); (void)hipStreamSynchronize(pp.s_out); }
+    if (err) {
+        (void)hipStreamSynchronize(pp.s_in); (void)hipStreamSynchronize(pp.s_out);
+        for (int k = 0; k < kHostSlots; k++) (void)hipStreamSynchronize(pp.s_k[k]);
+    }
     return err;
 }
 
