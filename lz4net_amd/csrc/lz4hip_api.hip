@@ -303,7 +303,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {
-        const unsigned waves = 4, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
+        const unsigned waves = kWaveDecodeWavesPerGroup, grid = (unsigned)((d.n_blocks + waves - 1) / waves);
         if (known) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
         else       hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * waves), 0, stream, d, wave_filter);
         count_dispatch(LZ4HIP_K_DECODE_WAVE);

@@ -16,8 +16,13 @@
 //  * long matches use the periodicity of an overlapping LZ77 copy: once `offset` bytes exist, the
 //    data is periodic, so the copy distance can be doubled every pass until it reaches 1 KiB and
 //    the remainder streams at 16 B per lane even for offset 1 (e.g. an all-zero block).
-//  Output is written straight to HBM (the 64 KiB window of a block is its own output, served from
-//  L2); no LDS is used, so residency is bounded by registers only (8 waves per SIMD).
+//  Output is written straight to HBM.  A short sequence also leaves its bytes in a 4 KiB ring in LDS that mirrors the
+//  wavefront's most recent output and takes its match bytes from there when the match starts inside it: on gfx9 one
+//  counter (vmcnt) covers loads AND stores, so a gather from global memory waits for every store issued before it --
+//  the write acknowledgement of the previous sequence, ~0.5 us -- while the ring's gather is an LDS access and the
+//  stores to HBM are never waited for.  Matches that reach further back, and everything after a long copy until the
+//  ring has filled up again, gather from global memory.  16 KiB of LDS per workgroup of four wavefronts leaves the
+//  residency where the registers put it.
 //
 // Return values are the reference's: known-size decode returns the number of source bytes consumed
 // or -(position of the error in the source); unknown-size decode returns bytes produced or
@@ -53,6 +58,7 @@ struct SrcWindow {
         const int o = wv::lane() * 4;
         w0 = fetch(o);
         w1 = fetch(256 + o);
+        wv::wait_vector_memory();
     }
     // make [p, p + n) addressable, n <= 256
     LZ4HIP_DEVICE void need(int p, int n)
@@ -63,6 +69,7 @@ struct SrcWindow {
             w0 = (nb == base + 256) ? w1 : fetch(nb + o);
             w1 = fetch(nb + 256 + o);
             base = nb;
+            wv::wait_vector_memory();                                // (once per 256 bytes of input: see wait_vector_memory)
         }
     }
     // wave-uniform byte at wave-uniform position p
@@ -72,6 +79,16 @@ struct SrcWindow {
         const int idx = p - base, l = idx >> 2;
         const uint32_t a = wv::readlane(w0, l & 63), b = wv::readlane(w1, l & 63);
         return (((l & 64) ? b : a) >> ((idx & 3) * 8)) & 255u;
+    }
+    // the bytes at wave-uniform position p, p + 1, ... in the low bytes of a wave-uniform 64-bit value: at least FIVE of
+    // them are valid (two window dwords, any byte phase); caller guarantees [p, p + 8) inside the window (need(p, 8))
+    LZ4HIP_DEVICE uint64_t peek5(int p) const
+    {
+        const int idx = p - base, l = idx >> 2, l1 = l + 1;
+        const uint32_t a = wv::readlane(w0, l & 63), b = wv::readlane(w1, l & 63);
+        const uint32_t c = wv::readlane(w0, l1 & 63), d = wv::readlane(w1, l1 & 63);
+        const uint64_t lo = (l & 64) ? b : a, hi = (l1 & 64) ? d : c;
+        return ((hi << 32) | lo) >> ((idx & 3) * 8);
     }
     // per-lane byte at per-lane position p (caller guarantees p inside the window)
     LZ4HIP_DEVICE uint32_t gather(int p) const
@@ -112,18 +129,51 @@ LZ4HIP_DEVICE void wave_match_copy(uint8_t* dst, int pos, int off, int n)
     }
 }
 
+constexpr int kWaveRingBytes = 4096;     // LDS mirror of a wavefront's most recent output (power of two)
+
 template <bool KNOWN>
-LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, int out_size)
+LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, int out_size, unsigned char* ring)
 {
     const int lane = wv::lane();
     const int iend = src_len, oend = out_size;
     int ip = 0, op = 0;
+    int ring_from = 0;                  // output bytes [max(ring_from, op - kWaveRingBytes), op) are in the ring
 
     if (!KNOWN && iend == 0) return 0;                      // original/lz4.c:946 returns -(0)
     SrcWindow win;
     win.init(src, src_len);
 
+    const int lane8 = (lane < 3 ? lane : 3) * 8;
     for (;;) {
+        // ---- the common short sequence in one step: at most two literals and a match whose length is in the token (4..18).
+        //      Token, literals and offset are the five bytes at ip: one look at the register window, no length bytes, one
+        //      byte-per-lane gather and store.  Anything else -- longer runs, length bytes, the last sequence, every
+        //      error -- takes the general path below, which also remains the definition of the semantics. ----
+        {
+            win.need(ip, 8);
+            const uint64_t t5 = win.peek5(ip);
+            const int tll = (int)((t5 >> 4) & 15u), tmlc = (int)(t5 & 15u);
+            const int t_lit_end = op + tll, t_ml = tmlc + kMinMatch, t_end = t_lit_end + t_ml;
+            const int t_off = (int)((t5 >> (8 + 8 * (tll & 3))) & 0xFFFFu);
+            const int t_ref = t_lit_end - t_off;
+            const bool not_last = KNOWN ? (t_lit_end <= oend - 8) : (t_lit_end <= oend - kMfLimit && ip + 1 + tll <= iend - 8);
+            if (tll <= 2 && tmlc != 15 && ip + 3 + tll <= iend && not_last && t_off != 0 && t_ref >= 0 && t_end <= oend - kLastLiterals) {
+                const uint32_t lit16 = (uint32_t)(t5 >> 8) & 0xFFFFu;
+                const int j = lane - tll;
+                int jj = j < 0 ? 0 : j;
+                if (t_off < t_ml) jj = jj % t_off;                   // byte-wise overlap semantics (wave-uniform branch)
+                const int sidx = t_ref + jj, from_lit = sidx - op;   // from_lit >= 0: one of THIS sequence's literals
+                const int ring_lo = op - kWaveRingBytes > ring_from ? op - kWaveRingBytes : ring_from;
+                uint32_t v = lit16 >> lane8;                         // lanes < tll: their literal
+                if (j >= 0 && j < t_ml)
+                    v = from_lit >= 0 ? lit16 >> (8 * (from_lit & 1))
+                                      : (sidx >= ring_lo ? (uint32_t)ring[sidx & (kWaveRingBytes - 1)] : (uint32_t)dst[sidx]);
+                if (lane < tll + t_ml) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
+                wv::mem_sync();
+                ip += 3 + tll; op = t_end;
+                continue;
+            }
+        }
         // ---- token + literal length: lz4.c:843-844 / :953-961 ----
         const uint32_t token = win.peek(ip); ip++;
         int ll = (int)(token >> 4);
@@ -181,10 +231,12 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
             const int sidx = ref + jj;                       // source index in dst
             const int from_lit = sidx - op;                  // >= 0: the byte is one of THIS sequence's literals
             const uint32_t via_lit = wv::shuffle(lit_byte, from_lit < 0 ? 0 : from_lit);
+            const int ring_lo = op - kWaveRingBytes > ring_from ? op - kWaveRingBytes : ring_from;
             uint32_t v = lit_byte;
-            if (in_match) v = from_lit >= 0 ? via_lit : (uint32_t)dst[sidx];
-            if (lane < ll || in_match) dst[op + lane] = (uint8_t)v;
+            if (in_match) v = from_lit >= 0 ? via_lit : (sidx >= ring_lo ? (uint32_t)ring[sidx & (kWaveRingBytes - 1)] : (uint32_t)dst[sidx]);
+            if (lane < ll || in_match) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
         } else {
+            ring_from = match_end;                           // the long copies below bypass the ring
             if (ll > 0) {
                 if (short_lit) { if (lane < ll) dst[op + lane] = (uint8_t)lit_byte; }
                 else wave_copy(dst + op, src + ip, ll);
@@ -198,9 +250,12 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
 }
 
 // grid: ceil(n_blocks / waves_per_group) workgroups of 64 * waves_per_group threads.
+constexpr int kWaveDecodeWavesPerGroup = 4;
+
 template <bool KNOWN>
-__global__ void __launch_bounds__(256) decode_kernel(Batch b, int filter)
+__global__ void __launch_bounds__(64 * kWaveDecodeWavesPerGroup) decode_kernel(Batch b, int filter)
 {
+    LZ4HIP_STATIC_LDS(rings, kWaveDecodeWavesPerGroup * kWaveRingBytes);
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv::wave_in_block();
     if (blk >= b.n_blocks) return;
     const int src_len = wv::uniform(batch_src_len(b, blk));
@@ -208,7 +263,7 @@ __global__ void __launch_bounds__(256) decode_kernel(Batch b, int filter)
     if (!block_selected(filter, src_len, out_size)) return;
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);
-    const int r = decode_block<KNOWN>(src, src_len, dst, out_size);
+    const int r = decode_block<KNOWN>(src, src_len, dst, out_size, rings + wv::wave_in_block() * kWaveRingBytes);
     if (wv::lane() == 0) b.result[blk] = r;
 }
 

@@ -63,6 +63,11 @@ LZ4HIP_DEVICE void mem_sync()
 
 LZ4HIP_DEVICE void block_sync() { __syncthreads(); }
 
+// s_waitcnt vmcnt(0): every vector-memory access this wave has issued has finished.  Used right after a RARE load whose
+// destination registers are read in a hot loop: the compiler otherwise has to assume at the loop header that the load may
+// still be in flight and puts the wait (which on gfx9 also covers every store issued since) in front of the hot reads.
+LZ4HIP_DEVICE void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi, lo} (0..3 -> lo, 4..7 -> hi; 0x0C -> 0x00).
 LZ4HIP_DEVICE uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // v_alignbyte_b32: ({hi, lo} >> 8 * n) truncated to 32 bits; callers keep n in 0..3.

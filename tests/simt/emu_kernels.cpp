@@ -38,8 +38,9 @@ void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     const unsigned wpg = (unsigned)waves_per_group;
     dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
-    if (known) simt::launch(grid, block, 0, [=] { decode_kernel<true>(b, filter); });
-    else       simt::launch(grid, block, 0, [=] { decode_kernel<false>(b, filter); });
+    const size_t lds = (size_t)wpg * kWaveRingBytes;
+    if (known) simt::launch(grid, block, lds, [=] { decode_kernel<true>(b, filter); });
+    else       simt::launch(grid, block, lds, [=] { decode_kernel<false>(b, filter); });
 }
 
 void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
