@@ -113,6 +113,7 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
     int final_seen = 0;          // the last sequence has been parsed
     int final_run = 0, result = 0;
     int done = 0;
+    int flush_blocked = 0;       // last iteration's far fetch had to wait for bytes that are not in global memory yet
     if (!active || (!KNOWN && iend == 0)) { done = 1; final_seen = 1; }   // lz4.c:946 returns -(0)
     // cooperative line loads in flight (helper role): data, destination in the staging area
     uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
@@ -164,16 +165,8 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         const bool x_ok = ip + 16 <= iend;                           // the 16 bytes are inside the source ...
         const bool x_have = in_have - A >= 16;                       // ... and staged
 
-        // =========================== (2) size of this iteration's chunk of the current copy ===========================
         const bool lit_slow = (mode == kLLit) & !x_ok;               // the last bytes of the source: byte-wise
-        // this iteration's appends (<= 16 + 11 bytes, written with up to 19 bytes of overshoot) must not reach unflushed output
-        const bool room = op - flushed <= R - 46;
-        const bool can = room & (rem > 0) & !((mode == kLGlobal) & (gready == 0)) & !((mode == kLLit) & x_ok & !x_have);
-        int n = can ? (rem < stride ? rem : stride) : 0;
-        const bool slow8 = can & (lit_slow | (mode == kLZeroOff));    // (branch-free: bitwise operators on purpose, the
-        n = (slow8 & (n > 8)) ? 8 : n;                               //  short-circuit forms compile to exec-mask branches)
         const int op_end = op + rem;                                 // where the current copy ends = where the parsed-ahead sequence starts
-        const int rem_after = rem - n;
 
         // =========================== (3) parse ahead ===========================
         const bool cursor_busy = (mode == kLLit) & (rem > 0);
@@ -276,12 +269,56 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
             v2 = near ? wv::perm(r3, r2, sr) : (lit ? x2 : us2);
             v3 = near ? wv::perm(r4, r3, sr) : (lit ? x3 : us3);
             LZ4HIP_KEEP(v0); LZ4HIP_KEEP(v1); LZ4HIP_KEEP(v2); LZ4HIP_KEEP(v3);
-            if (can && (lit_slow || mode == kLZeroOff)) {             // rare byte-wise sources, 8 bytes at a time
-                uint64_t acc = 0;
-                if (lit_slow) { for (int b = 0; b < n; b++) if (ip + b < iend) acc |= (uint64_t)src[ip + b] << (8 * b); }
-                else          { for (int b = 0; b < n; b++) acc |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
-                v0 = (uint32_t)acc; v1 = (uint32_t)(acc >> 32);
+        }
+
+        // =========================== (7) flush finished output, 64 bytes at a time, four lanes per line ===========================
+        // (placed right after the iteration's only vector-memory wait: on gfx9 vmcnt counts stores as well, so stores issued just
+        //  BEFORE the wait -- at the end of the previous iteration, where this block used to be -- made every iteration that
+        //  followed a flush wait for the write acknowledgements; here they have a whole iteration)
+        {
+            const bool need = (done == 0) & (op - flushed >= 64);
+            const bool urgent = need & ((op - flushed >= kFlushUrgent) | (flush_blocked != 0) | ((final_run != 0) & (rem == 0)));
+            const uint64_t needy = wv::ballot(need);
+            const int cnt_all = wv::popc64(needy);
+            if (cnt_all >= 16 || wv::any(urgent)) {                  // wave-uniform
+                const int cnt = cnt_all < kDecFlushRecs ? cnt_all : kDecFlushRecs;
+                const int frank = wv::rank_below(needy);
+                const bool mine = need & (frank < kDecFlushRecs);     // (the others come next iteration)
+                if (mine) {
+                    const uint64_t dp = (uint64_t)dst;
+                    flush_rec[frank] = Aligned16{ { (uint32_t)lane, (uint32_t)flushed, (uint32_t)dp, (uint32_t)(dp >> 32) } };
+                }
+                wv::mem_sync();
+                const int sub = lane & 3;
+                for (int base = 0; base < cnt; base += 16) {         // wave-uniform trip count
+                    const int idx = base + (lane >> 2);
+                    if (idx < cnt) {
+                        const Aligned16 r = flush_rec[idx];
+                        const int fj = (int)r.w[1];
+                        const uint64_t dj = (uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32);
+                        // 16 dwords of lane r.w[0]'s ring from fj (a multiple of 64: no wrap), this lane takes 4 of them
+                        const uint32_t* fp = (const uint32_t*)(lds + ((((uint32_t)fj << 6) & kRingMask) | (r.w[0] << 2))) + 4 * sub * 64;
+                        wv::store_global16(dj + (uint64_t)(fj + 16 * sub), fp[0], fp[64], fp[128], fp[192]);
+                    }
+                }
+                wv::mem_sync();                                      // records and ring bytes are free to be overwritten again
+                flushed += mine ? 64 : 0;
             }
+        }
+
+        // =========================== (2) size of this iteration's chunk of the current copy ===========================
+        // this iteration's appends (<= 16 + 11 bytes, written with up to 19 bytes of overshoot) must not reach unflushed output
+        const bool room = op - flushed <= R - 46;
+        const bool can = room & (rem > 0) & !((mode == kLGlobal) & (gready == 0)) & !((mode == kLLit) & x_ok & !x_have);
+        int n = can ? (rem < stride ? rem : stride) : 0;
+        const bool slow8 = can & (lit_slow | (mode == kLZeroOff));    // (branch-free: bitwise operators on purpose, the
+        n = (slow8 & (n > 8)) ? 8 : n;                               //  short-circuit forms compile to exec-mask branches)
+        const int rem_after = rem - n;
+        if (can && (lit_slow || mode == kLZeroOff)) {                 // rare byte-wise sources, 8 bytes at a time
+            uint64_t acc = 0;
+            if (lit_slow) { for (int b = 0; b < n; b++) if (ip + b < iend) acc |= (uint64_t)src[ip + b] << (8 * b); }
+            else          { for (int b = 0; b < n; b++) acc |= (uint64_t)dst[op + b] << (8 * b); }   // offset 0: keep what dst holds
+            v0 = (uint32_t)acc; v1 = (uint32_t)(acc >> 32);
         }
 
         // =========================== (4a) input staging: land last iteration's pieces, request new ones ===========================
@@ -338,7 +375,7 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
             const Vec16 w = load_v16(dst + f_pos);
             ld0 = w.w[0]; ld1 = w.w[1]; ld2 = w.w[2]; ld3 = w.w[3];
         }
-        const bool flush_blocked = f_want & !f_do;
+        flush_blocked = (f_want & !f_do) ? 1 : 0;                    // (read by the flush of the NEXT iteration)
 
         // =========================== (5b) append the chunk ===========================
         {
@@ -377,38 +414,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         }
         nx = promote ? 0 : nx;
         gready = ((mode == kLGlobal) & f_do) ? 1 : 0;
-
-        // =========================== (7) flush finished output, 64 bytes at a time, four lanes per line ===========================
-        {
-            const bool need = (done == 0) & (op - flushed >= 64);
-            const bool urgent = need & ((op - flushed >= kFlushUrgent) | flush_blocked | ((final_run != 0) & (rem == 0)));
-            const uint64_t needy = wv::ballot(need);
-            const int cnt_all = wv::popc64(needy);
-            if (cnt_all >= 16 || wv::any(urgent)) {                  // wave-uniform
-                const int cnt = cnt_all < kDecFlushRecs ? cnt_all : kDecFlushRecs;
-                const int frank = wv::rank_below(needy);
-                const bool mine = need & (frank < kDecFlushRecs);     // (the others come next iteration)
-                if (mine) {
-                    const uint64_t dp = (uint64_t)dst;
-                    flush_rec[frank] = Aligned16{ { (uint32_t)lane, (uint32_t)flushed, (uint32_t)dp, (uint32_t)(dp >> 32) } };
-                }
-                wv::mem_sync();
-                const int sub = lane & 3;
-                for (int base = 0; base < cnt; base += 16) {         // wave-uniform trip count
-                    const int idx = base + (lane >> 2);
-                    if (idx < cnt) {
-                        const Aligned16 r = flush_rec[idx];
-                        const int fj = (int)r.w[1];
-                        const uint64_t dj = (uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32);
-                        // 16 dwords of lane r.w[0]'s ring from fj (a multiple of 64: no wrap), this lane takes 4 of them
-                        const uint32_t* fp = (const uint32_t*)(lds + ((((uint32_t)fj << 6) & kRingMask) | (r.w[0] << 2))) + 4 * sub * 64;
-                        wv::store_global16(dj + (uint64_t)(fj + 16 * sub), fp[0], fp[64], fp[128], fp[192]);
-                    }
-                }
-                wv::mem_sync();                                      // records and ring bytes are free to be overwritten again
-                flushed += mine ? 64 : 0;
-            }
-        }
 
         if (final_run && rem == 0 && !nx && !done) {
             // ---- end of block: write out the last bytes exactly ----
