@@ -358,7 +358,7 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
     not -- same bytes and same return codes as the oracle for both decoders, every mapping, nothing written past the
     capacity."""
     import stream_fuzz
-    cs = stream_fuzz.cases(99, 600)
+    cs = stream_fuzz.cases(99, 600) + stream_fuzz.cases(100, 150, max_size=20000)    # (the longer ones wrap the decoders' rings)
     comps = [c for (c, _), _ in cs]
     sizes = [t for _, t in cs]
     pad = [np.concatenate([c, np.zeros(t + 1024, np.uint8)]) for c, t in zip(comps, sizes)]

@@ -264,7 +264,7 @@ def test_decode_arbitrary_streams(oracle, lane):
     them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching
     a byte past the capacity."""
     import stream_fuzz
-    cs = stream_fuzz.cases(2026, 240)
+    cs = stream_fuzz.cases(2026, 240) + stream_fuzz.cases(2027, 24, max_size=12000)  # (the longer ones wrap the decoders' rings)
     comps = [c for (c, _), _ in cs]
     sizes = [t for _, t in cs]
     for (c, raw), t in cs:
