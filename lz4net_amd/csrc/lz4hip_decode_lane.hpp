@@ -136,9 +136,8 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         const uint32_t a1_ = wv::perm(d1_, d0_, s_), a2_ = wv::perm(d2_, d1_, s_);                      \
         const uint32_t a3_ = wv::perm(d3_, d2_, s_), a4_ = wv::perm(0u, d3_, s_);                       \
         RING_AT(k_, 0) = a0_; RING_AT(k_, 1) = a1_; RING_AT(k_, 2) = a2_; RING_AT(k_, 3) = a3_; RING_AT(k_, 4) = a4_; \
-        const uint32_t t_ = (sb_ + (uint32_t)(n_)) >> 2;                                                \
-        tail = t_ < 2 ? (t_ == 0 ? a0_ : a1_) : (t_ == 2 ? a2_ : (t_ == 3 ? a3_ : a4_));                \
         op += (n_);                                                                                     \
+        tail = RING_AT(op, 0);                                                                          \
     } while (0)
 #define APPEND3(d0_, d1_, d2_, n_)                                                                      \
     do {                                                                                                \
@@ -146,9 +145,8 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         const uint32_t a0_ = (tail & keep_) | wv::perm(d0_, 0u, s_);                                    \
         const uint32_t a1_ = wv::perm(d1_, d0_, s_), a2_ = wv::perm(d2_, d1_, s_), a3_ = wv::perm(0u, d2_, s_); \
         RING_AT(k_, 0) = a0_; RING_AT(k_, 1) = a1_; RING_AT(k_, 2) = a2_; RING_AT(k_, 3) = a3_;         \
-        const uint32_t t_ = (sb_ + (uint32_t)(n_)) >> 2;                                                \
-        tail = t_ < 2 ? (t_ == 0 ? a0_ : a1_) : (t_ == 2 ? a2_ : a3_);                                  \
         op += (n_);                                                                                     \
+        tail = RING_AT(op, 0);                                                                          \
     } while (0)
     // selector that extracts 4 bytes at byte phase (p & 3) from a dword pair: wv::perm(hi, lo, PHASE_SEL(p))
 #define PHASE_SEL(p_) wv::alignbyte(0x07060504u, 0x03020100u, (uint32_t)(p_) & 3u)
