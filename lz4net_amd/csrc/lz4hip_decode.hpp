@@ -144,34 +144,43 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
     win.init(src, src_len);
 
     const int lane8 = (lane < 3 ? lane : 3) * 8;
+    // While op <= o_safe and ip <= i_safe a sequence of at most 2 literals and a match of at most 18 bytes can neither be
+    // the last one (lz4.c:851 / :965) nor run into the end of the output (:893 / :1024) nor read past the source.
+    const int o_safe = KNOWN ? oend - 28 : oend - 32;
+    const int i_safe = KNOWN ? iend - 5 : iend - 11;
     for (;;) {
-        // ---- the common short sequence in one step: at most two literals and a match whose length is in the token (4..18).
-        //      Token, literals and offset are the five bytes at ip: one look at the register window, no length bytes, one
-        //      byte-per-lane gather and store.  Anything else -- longer runs, length bytes, the last sequence, every
-        //      error -- takes the general path below, which also remains the definition of the semantics. ----
-        {
+        // ---- the common short sequence in one step: at most two literals and a match whose length is in the token (4..18),
+        //      whose source neither overlaps the match itself nor this sequence's literals.  Token, literals and offset are
+        //      the five bytes at ip: one look at the register window, no length bytes, one byte-per-lane gather and store.
+        //      Anything else -- longer runs, length bytes, overlapping matches, the last sequence, every error -- takes the
+        //      general path below, which also remains the definition of the semantics. ----
+        if (op <= o_safe && ip <= i_safe) {
             win.need(ip, 8);
             const uint64_t t5 = win.peek5(ip);
             const int tll = (int)((t5 >> 4) & 15u), tmlc = (int)(t5 & 15u);
-            const int t_lit_end = op + tll, t_ml = tmlc + kMinMatch, t_end = t_lit_end + t_ml;
-            const int t_off = (int)((t5 >> (8 + 8 * (tll & 3))) & 0xFFFFu);
-            const int t_ref = t_lit_end - t_off;
-            const bool not_last = KNOWN ? (t_lit_end <= oend - 8) : (t_lit_end <= oend - kMfLimit && ip + 1 + tll <= iend - 8);
-            if (tll <= 2 && tmlc != 15 && ip + 3 + tll <= iend && not_last && t_off != 0 && t_ref >= 0 && t_end <= oend - kLastLiterals) {
-                const uint32_t lit16 = (uint32_t)(t5 >> 8) & 0xFFFFu;
-                const int j = lane - tll;
-                int jj = j < 0 ? 0 : j;
-                if (t_off < t_ml) jj = jj % t_off;                   // byte-wise overlap semantics (wave-uniform branch)
-                const int sidx = t_ref + jj, from_lit = sidx - op;   // from_lit >= 0: one of THIS sequence's literals
-                const int ring_lo = op - kWaveRingBytes > ring_from ? op - kWaveRingBytes : ring_from;
-                uint32_t v = lit16 >> lane8;                         // lanes < tll: their literal
-                if (j >= 0 && j < t_ml)
-                    v = from_lit >= 0 ? lit16 >> (8 * (from_lit & 1))
-                                      : (sidx >= ring_lo ? (uint32_t)ring[sidx & (kWaveRingBytes - 1)] : (uint32_t)dst[sidx]);
-                if (lane < tll + t_ml) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
-                wv::mem_sync();
-                ip += 3 + tll; op = t_end;
-                continue;
+            if (tll <= 2 && tmlc != 15) {
+                const int t_lit_end = op + tll, t_ml = tmlc + kMinMatch;
+                const int t_off = (int)((t5 >> (8 + 8 * tll)) & 0xFFFFu);
+                if (t_off >= t_ml + tll && t_off <= t_lit_end) {
+                    const int t_ref = t_lit_end - t_off;
+                    const int ring_lo = op - kWaveRingBytes > ring_from ? op - kWaveRingBytes : ring_from;
+                    const int sidx = t_ref + lane - tll;             // source of this lane's match byte (lanes >= tll)
+                    const uint32_t lit = (uint32_t)(t5 >> 8) >> lane8;             // lanes < tll: their literal
+                    // (two copies of the store on purpose: the one behind the LDS gather must not inherit the global
+                    //  gather's vmcnt wait, which on gfx9 would also wait for the previous sequence's store)
+                    if (t_ref >= ring_lo) {                                        // wave-uniform: the whole match is in the LDS mirror
+                        uint32_t v = ring[sidx & (kWaveRingBytes - 1)];
+                        if (lane < tll) v = lit;
+                        if (lane < tll + t_ml) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
+                    } else {
+                        uint32_t v = lane >= tll && lane < tll + t_ml ? (uint32_t)dst[sidx] : 0u;
+                        if (lane < tll) v = lit;
+                        if (lane < tll + t_ml) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
+                    }
+                    wv::mem_sync();
+                    ip += 3 + tll; op = t_lit_end + t_ml;
+                    continue;
+                }
             }
         }
         // ---- token + literal length: lz4.c:843-844 / :953-961 ----
