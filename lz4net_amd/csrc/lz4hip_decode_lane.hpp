@@ -40,7 +40,10 @@
 
 namespace lz4hip {
 
-constexpr int kDecFlushRecs = 32;                         // flush records (lines stored per flush round, two store instructions)
+#ifndef LZ4HIP_DEC_FLUSH_RECS
+#define LZ4HIP_DEC_FLUSH_RECS 32      /* the emulator also builds a 'starved' variant with 4 (tests/simt/build_emu.py) */
+#endif
+constexpr int kDecFlushRecs = LZ4HIP_DEC_FLUSH_RECS;          // flush records (lines stored per flush round, two store instructions)
 constexpr int kDecFlushRecBytes = 16 * kDecFlushRecs;
 constexpr int kDecLoadRecBytes = 512;                     // up to 32 piece-load records
 // LDS of one wavefront: 64 output rings, 64 input staging rings (both dword-interleaved across the lanes), the
@@ -103,7 +106,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
                                  // produced is periodic with period off, hence with period 2*off): 1, 2, 4, 8, then 16 bytes per iteration
     uint32_t fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0, fb0 = 0, fb1 = 0, fb2 = 0, fb3 = 0;   // far-match data, by iteration parity
     int gready = 0;              // kLGlobal: the 16 bytes fetched in the previous iteration are this lane's next chunk
-    int gpos = 0;                // kLGlobal: position in dst of the next 16 bytes to fetch
     // parsed-ahead sequence
     int nx = 0;                  // there is one
     int n_ll = 0, n_stream = 0, n_ml = 0, n_off = 8, n_hasmatch = 0, n_final = 0, n_result = 0, n_err = 0;
@@ -366,7 +368,10 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         // copy ends in this iteration (then the sequence is promoted below and its match starts next iteration)
         const bool f_cont = (mode == kLGlobal) & (rem_after > 0);
         const bool f_first = (rem_after == 0) & room & (nx != 0) & (n_hasmatch != 0) & (n_err == 0) & (n_off > kNearMax);
-        const int f_pos = f_cont ? gpos : op_end + n_ll - n_off;
+        // (the source of the chunk that will be appended at output position p is p - off: no separate fetch cursor, so a lane
+        //  that holds fetched bytes but could not append them -- it missed two flush rounds in a row, its ring is full --
+        //  simply fetches the same 16 bytes again; tests/test_simt_emulation.py::test_lane_decoder_starved_flush)
+        const int f_pos = f_cont ? op + n - off : op_end + n_ll - n_off;
         const bool f_want = f_cont | f_first;
         const bool f_do = f_want & (f_pos + 16 <= flushed);
         if (f_do) {
@@ -383,7 +388,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
             const bool grow = near & (off < 16) & (n > 0);
             off = grow ? off * 2 : off;
             stride = grow ? (off < 16 ? off : 16) : stride;
-            gpos += (f_cont & f_do) ? 16 : 0;
             mode = rem == 0 ? (int)kLIdle : mode;
         }
 
@@ -407,7 +411,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
             off = n_off;
             stride = ((off >= 16) | (off == 0)) ? 16 : off;          // at most `off` bytes while the source would overlap the chunk
             mode = off == 0 ? (int)kLZeroOff : (off <= kNearMax ? (int)kLNear : (int)kLGlobal);
-            gpos = op - off + (f_do ? 16 : 0);                       // (f_do here: the prefetch above was this match's first 16 bytes)
             rem = n_ml;
         }
         nx = promote ? 0 : nx;

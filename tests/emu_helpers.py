@@ -10,15 +10,34 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim
 from build_emu import build  # noqa: E402
 
 _lib = None
+_starved = None
+_use_starved = False
 
 
 def lib():
-    global _lib
+    global _lib, _starved
+    if _use_starved:
+        if _starved is None:
+            _starved = C.CDLL(build(starved=True))
+        return _starved
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.emu_compare.restype = C.c_ulonglong
         _lib.emu_steps.restype = C.c_ulonglong
     return _lib
+
+
+class starved_flush:
+    """with emu.starved_flush(): ...  -- run the kernels of the 'starved' build (4 flush records per round)."""
+
+    def __enter__(self):
+        global _use_starved
+        _use_starved = True
+
+    def __exit__(self, *a):
+        global _use_starved
+        _use_starved = False
+        return False
 
 
 def _p(a):

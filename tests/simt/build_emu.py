@@ -10,12 +10,18 @@ CSRC = os.path.join(ROOT, "lz4net_amd", "csrc")
 SO = os.path.join(HERE, "libsimt_kernels.so")
 
 
-def build() -> str:
+def build(starved: bool = False) -> str:
+    """starved=True: the same kernels with the lane decoder's cooperative flush cut down to 4 lines per round, so that
+    lanes miss flush rounds again and again and run their rings full -- the rare states of the lane decoder (a lane that
+    cannot append, a far-match chunk fetched but not consumed) become the common ones."""
+    so = SO.replace(".so", "_starved.so") if starved else SO
     deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "*.hpp")) + \
         [os.path.join(HERE, "emu_kernels.cpp")]
-    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         flags = ["-DLZ4HIP_HAVE_HC"] if os.path.exists(os.path.join(CSRC, "lz4hip_hc.hpp")) else []
+        if starved:
+            flags.append("-DLZ4HIP_DEC_FLUSH_RECS=4")
         subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused",
-                        "-I" + HERE, "-I" + CSRC, *flags, "-o", SO, os.path.join(HERE, "emu_kernels.cpp")],
+                        "-I" + HERE, "-I" + CSRC, *flags, "-o", so, os.path.join(HERE, "emu_kernels.cpp")],
                        check=True)
-    return SO
+    return so

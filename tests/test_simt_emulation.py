@@ -258,6 +258,34 @@ def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
+def test_lane_decoder_starved_flush(oracle):
+    """The lane decoder with its cooperative flush cut down to 4 lines per round: with 64 busy lanes most of them miss
+    flush rounds several times in a row, run their output rings full and sit out iterations -- also while the first or the
+    next 16 bytes of a far match have already been fetched for them (those must be fetched again, not skipped).  Blocks:
+    the lock-step block of the test above (far matches of every length) in 64 copies, and 64 different record-like /
+    fuzzer-style blocks."""
+    rng = np.random.default_rng(29)
+    data = bytearray(rng.integers(0, 256, 5000, dtype=np.uint8).tobytes())
+    for off in (130, 200, 236, 260, 500, 1000, 4097):
+        for ml in list(range(4, 70, 3)):
+            data += rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8).tobytes()
+            start = len(data) - off
+            for i in range(ml):
+                data.append(data[start + i])
+            data.append(int(rng.integers(0, 256)))
+    block = np.frombuffer(bytes(data), dtype=np.uint8)
+    sets = [[block] * 64, [oracle.gen(3 if i % 2 else 2, 41, i, 1, 6000 + 37 * i)[0] for i in range(64)]]
+    with emu.starved_flush():
+        for blocks in sets:
+            comps = [oracle.compress(a) for a in blocks]
+            for known in (True, False):
+                res, dst = emu.decode([np.concatenate([c, np.zeros(64, np.uint8)]) for c in comps], [a.size for a in blocks], known=known,
+                                      src_lens=None if known else [len(c) for c in comps], lane=128, stage=64)
+                for i, (a, c) in enumerate(zip(blocks, comps)):
+                    assert res[i] == (len(c) if known else a.size), (known, i, res[i])
+                    assert np.array_equal(dst[i, :a.size], a), (known, i)
+
+
 @pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
 def test_decode_arbitrary_streams(oracle, lane):
     """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
