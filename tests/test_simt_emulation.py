@@ -284,6 +284,9 @@ def test_lane_decoder_starved_flush(oracle):
                 for i, (a, c) in enumerate(zip(blocks, comps)):
                     assert res[i] == (len(c) if known else a.size), (known, i, res[i])
                     assert np.array_equal(dst[i, :a.size], a), (known, i)
+        # the odd-but-legal and malformed streams and the error-code matrix, in the same starved state
+        test_decode_arbitrary_streams(oracle, "lane128s64")
+        test_decode_error_codes_match_oracle(oracle, "lane128s64")
 
 
 @pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
