@@ -69,7 +69,11 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
     static_assert(SB == 64 || SB == 128, "staging ring: 64 or 128 bytes per lane");
     constexpr int PIECE = SB / 2;                                    // the input arrives in aligned pieces of half a staging ring
     constexpr int HELPERS = PIECE / 16;                              // lanes that load one piece (16 bytes each)
+#ifdef LZ4HIP_DEC_LOAD_PIECES                                        /* the emulator's 'starved' build: 2 pieces per round */
+    constexpr int PIECES_PER_LOAD = LZ4HIP_DEC_LOAD_PIECES;
+#else
     constexpr int PIECES_PER_LOAD = 64 / HELPERS;                    // pieces one load instruction brings in
+#endif
     constexpr uint32_t kStageMask = (uint32_t)(SB / 4 - 1) << 8;
     // An append writes whole dwords, up to 19 bytes past its last byte; those land on ring bytes op-R+19 and older.
     constexpr int kNearMax = R - 20;                                 // largest offset served from the ring

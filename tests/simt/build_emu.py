@@ -12,7 +12,8 @@ SO = os.path.join(HERE, "libsimt_kernels.so")
 
 def build(starved: bool = False) -> str:
     """starved=True: the same kernels with the lane decoder's cooperative flush cut down to 4 lines per round, so that
-    lanes miss flush rounds again and again and run their rings full -- the rare states of the lane decoder (a lane that
+    lanes miss flush rounds again and again and run their rings full (and its cooperative staging
+    load to 2 pieces per round, so that lanes run out of input) -- the rare states of the lane decoder (a lane that
     cannot append, a far-match chunk fetched but not consumed) become the common ones."""
     so = SO.replace(".so", "_starved.so") if starved else SO
     deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "*.hpp")) + \
@@ -20,7 +21,7 @@ def build(starved: bool = False) -> str:
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         flags = ["-DLZ4HIP_HAVE_HC"] if os.path.exists(os.path.join(CSRC, "lz4hip_hc.hpp")) else []
         if starved:
-            flags.append("-DLZ4HIP_DEC_FLUSH_RECS=4")
+            flags += ["-DLZ4HIP_DEC_FLUSH_RECS=4", "-DLZ4HIP_DEC_LOAD_PIECES=2"]
         subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused",
                         "-I" + HERE, "-I" + CSRC, *flags, "-o", so, os.path.join(HERE, "emu_kernels.cpp")],
                        check=True)
