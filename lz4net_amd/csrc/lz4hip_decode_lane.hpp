@@ -105,7 +105,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
     uint32_t tail = 0;           // ring dword containing op: its low (op & 3) bytes are output, the rest is junk
     // current copy
     int mode = kLIdle, rem = 0;
-    int stride = 16;             // bytes per chunk: 16, or the offset of a near match while that is smaller (source and chunk must not overlap)
     int off = 8;                 // offset of the current match; a near match with off < 16 DOUBLES it after every chunk (what has been
                                  // produced is periodic with period off, hence with period 2*off): 1, 2, 4, 8, then 16 bytes per iteration
     uint32_t fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0, fb0 = 0, fb1 = 0, fb2 = 0, fb3 = 0;   // far-match data, by iteration parity
@@ -314,6 +313,7 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         // this iteration's appends (<= 16 + 11 bytes, written with up to 19 bytes of overshoot) must not reach unflushed output
         const bool room = op - flushed <= R - 46;
         const bool can = room & (rem > 0) & !((mode == kLGlobal) & (gready == 0)) & !((mode == kLLit) & x_ok & !x_have);
+        const int stride = (near & (off < 16)) ? off : 16;          // bytes per chunk: at most `off` while a near match's source would overlap the chunk
         int n = can ? (rem < stride ? rem : stride) : 0;
         const bool slow8 = can & (lit_slow | (mode == kLZeroOff));    // (branch-free: bitwise operators on purpose, the
         n = (slow8 & (n > 8)) ? 8 : n;                               //  short-circuit forms compile to exec-mask branches)
@@ -391,7 +391,6 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
             rem = rem_after;
             const bool grow = near & (off < 16) & (n > 0);
             off = grow ? off * 2 : off;
-            stride = grow ? (off < 16 ? off : 16) : stride;
             mode = rem == 0 ? (int)kLIdle : mode;
         }
 
@@ -406,14 +405,12 @@ LZ4HIP_DEVICE int lane_decode_block(unsigned char* lds, int lane, bool active, c
         if (pgo) {
             rem = n_stream;
             mode = n_stream > 0 ? (int)kLLit : (int)kLIdle;
-            stride = 16;
             final_run = n_final;
             result = n_final ? n_result : result;
         }
         if (pgo & (n_hasmatch != 0)) {
             // ---- start the match copy: byte-wise semantics out[i] = out[i - off] ----
             off = n_off;
-            stride = ((off >= 16) | (off == 0)) ? 16 : off;          // at most `off` bytes while the source would overlap the chunk
             mode = off == 0 ? (int)kLZeroOff : (off <= kNearMax ? (int)kLNear : (int)kLGlobal);
             rem = n_ml;
         }
