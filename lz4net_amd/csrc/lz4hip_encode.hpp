@@ -30,21 +30,30 @@ template <> struct FastTable<true> {    // generic variant: U32 HashTable[4096],
 // wave-uniform unaligned dword of the input at wave-uniform position p
 LZ4HIP_DEVICE uint32_t input_word(const uint8_t* in, int p) { return wv::uniform(load_u32(in + p)); }
 
+// One lane's share of a 256-byte round of the count below: XOR of its dwords at in[a + off + 4*lane] and in[b + ...],
+// with a sentinel at the first byte that must not be counted (1 = "differs at byte 0" where nothing may be counted).
+LZ4HIP_DEVICE uint32_t common_length_round(const uint8_t* in, int a, int b, int limit, int off)
+{
+    const int pa = a + off + wv::lane() * 4;
+    int valid = limit - pa;                           // bytes of this lane's dword that may be counted
+    valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
+    uint32_t diff = 1;
+    if (valid > 0) {
+        diff = load_u32(in + pa) ^ load_u32(in + b + off + wv::lane() * 4);
+        if (valid < 4) diff |= 1u << (8 * valid);
+    }
+    return diff;
+}
+
 // Number of equal bytes in[a + i] == in[b + i] for i < limit - a (a > b), counted 4 bytes per lane.
 // Equals the reference's 8-byte XOR/ctz loop plus its 4/2/1-byte tails (lz4.c:698-721).
-LZ4HIP_DEVICE int wave_common_length(const uint8_t* in, int a, int b, int limit)
+// `first_round`: common_length_round(in, a, b, limit, 0), which the caller may have requested earlier (its loads then
+// travel together with those of the catch-up instead of costing a round trip of their own).
+LZ4HIP_DEVICE int wave_common_length(const uint8_t* in, int a, int b, int limit, uint32_t first_round)
 {
-    const int lane = wv::lane();
     int total = 0;
+    uint32_t diff = first_round;
     for (;;) {
-        const int pa = a + total + lane * 4;
-        int valid = limit - pa;                       // bytes of this lane's dword that may be counted
-        valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
-        uint32_t diff = 1;                            // valid == 0: "differs at byte 0"
-        if (valid > 0) {
-            diff = load_u32(in + pa) ^ load_u32(in + b + total + lane * 4);
-            if (valid < 4) diff |= 1u << (8 * valid); // sentinel at the first byte that must not count
-        }
         const uint64_t stop = wv::ballot(diff != 0);
         if (stop) {
             const int first = wv::ctz64(stop);
@@ -52,7 +61,13 @@ LZ4HIP_DEVICE int wave_common_length(const uint8_t* in, int a, int b, int limit)
             return total + first * 4 + (__builtin_ctz(d) >> 3);
         }
         total += 256;
+        diff = common_length_round(in, a, b, limit, total);
     }
+}
+
+LZ4HIP_DEVICE int wave_common_length(const uint8_t* in, int a, int b, int limit)
+{
+    return wave_common_length(in, a, b, limit, common_length_round(in, a, b, limit, 0));
 }
 
 // Number of bytes the match can be extended backwards: in[ip-1-i] == in[ref-1-i], i < bound.
@@ -188,10 +203,14 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
             if (!wave_find_match<GENERIC>(in, table, ip, ref, mflimit)) break;
 
             // ---- catch up: lz4.c:657 ----
+            // (the first 256 bytes of the forward count are requested before it: the bytes a catch-up adds in front lie
+            //  inside what is already known to be equal, so the forward count from the probe position is the same count)
+            uint32_t fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
+            int caught_up = 0;
             {
                 const int room = ip - anchor, bound = room < ref ? room : ref;
                 const int back = bound > 0 ? wave_catch_up(in, ip, ref, bound) : 0;
-                ip -= back; ref -= back;
+                ip -= back; ref -= back; caught_up = back;
             }
 
             // ---- literals: lz4.c:660-691 ----
@@ -213,7 +232,9 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
                 if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
                 op += 2;
                 ip += kMinMatch; ref += kMinMatch; anchor = ip;
-                ip += wave_common_length(in, ip, ref, matchlimit);
+                // (first sequence of a search: counted from the probe position, `caught_up` bytes further on)
+                ip += caught_up + wave_common_length(in, ip + caught_up, ref + caught_up, matchlimit, fwd_round);
+                caught_up = 0;
                 const int extra = ip - anchor;
                 if (op + (extra >> 8) > cap - 6) return 0;           // lz4.c:728
                 if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return 0;   // (see note above)
@@ -230,10 +251,11 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
                 if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
                 // ---- re-seed the table and test the next position: lz4.c:739-751 ----
                 {
-                    const uint32_t h2 = T::hash(input_word(in, ip - 2));
+                    const uint64_t w8 = wv::uniform(load_u64(in + ip - 2));   // bytes ip-2 .. ip+5 (ip <= mflimit): both words in one trip
+                    const uint32_t h2 = T::hash((uint32_t)w8);
                     if (lane == 0) table[h2] = (entry)(ip - 2);
                     wv::mem_sync();
-                    cur_word = input_word(in, ip);
+                    cur_word = (uint32_t)(w8 >> 16);
                     const uint32_t h = T::hash(cur_word);
                     ref = (int)wv::uniform((uint32_t)table[h]);
                     if (lane == 0) table[h] = (entry)ip;
@@ -242,6 +264,7 @@ LZ4HIP_DEVICE int encode_fast_block(const uint8_t* in, int n, uint8_t* out, int 
                 if (!(in_range && input_word(in, ref) == cur_word)) break;
                 token_at = op++;                                      // zero-literal sequence (lz4.c:751)
                 token = 0;
+                fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
             }
             anchor = ip++;                                            // lz4.c:754-755
         }
