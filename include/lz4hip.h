@@ -110,7 +110,7 @@ int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_siz
 int lz4hip_dispatch_counts(uint64_t* counts, int n);
 
 /* Frees the grow-only kernel workspaces (encoder hash-table / LZ4HC slabs) of the CURRENT device after
- * waiting for their last user.  The reference frees its tables before every return (original/lz4.c:780-786);
+ * waiting for their last user, and the calling thread's host-pointer staging (device images, pinned slots) for it.  The reference frees its tables before every return (original/lz4.c:780-786);
  * the library caches them between calls, this is how a caller gets the memory back. */
 int lz4hip_release_workspaces(void);
 

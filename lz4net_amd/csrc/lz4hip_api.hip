@@ -104,6 +104,7 @@ struct Scratch {
         }
         return 0;
     }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
     ~Scratch() { /* the HIP runtime may already be gone at thread exit: leak on purpose */ }
 };
 
@@ -327,6 +328,7 @@ struct Pinned {
         cap = want;
         return 0;
     }
+    void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
     ~Pinned() { /* see ~Scratch */ }
 };
 
@@ -681,6 +683,12 @@ int lz4hip_release_workspaces(void)
         if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
         HIP_TRY(hipFree(w.p));
         w.p = nullptr; w.cap = 0; w.busy = false;
+    }
+    // ... and the CALLING thread's host-pointer staging for this device (device images + pinned slots; the host-pointer
+    // entry points are synchronous, so nothing of this thread's is in flight here)
+    if (HostContext* hc = host_context(dev)) {
+        hc->scratch.release();
+        for (int k = 0; k < kHostSlots; k++) { hc->pin_in[k].release(); hc->pin_out[k].release(); }
     }
     return 0;
 }

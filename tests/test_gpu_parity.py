@@ -380,6 +380,24 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
         assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)
 
 
+def test_release_workspaces_then_reuse(gpu, oracle):
+    """lz4hip_release_workspaces() gives back the cached kernel workspaces and the calling thread's host-pointer staging;
+    the next calls simply allocate again and produce the same bytes."""
+    from lz4net_amd import _lib
+    blocks = [oracle.gen(2, 77, i, 1, 4096 + 11 * i)[0] for i in range(40)]
+    want = [oracle.compress(a) for a in blocks]
+    for _ in range(2):
+        res, dst = gpu.encode(blocks)
+        for i, w in enumerate(want):
+            assert res[i] == len(w) and np.array_equal(dst[i, :res[i]], w), i
+        res, dst = gpu.encode(blocks, hc=True)
+        for i, a in enumerate(blocks):
+            w = oracle.compress(a, hc=True)
+            assert res[i] == len(w) and np.array_equal(dst[i, :res[i]], w), i
+        _lib.check(_lib.lib().lz4hip_release_workspaces())
+        _lib.check(_lib.lib().lz4hip_release_workspaces())            # idempotent
+
+
 def test_multi_device_host_batches(gpu, oracle):
     """lz4hip_*_batch_host_multi (SURVEY.md 8b `deviceMask`, 8e): block i -> the (i mod N)-th selected device, results in
     global order.  Always with mask 0x1; with two devices (and with mask 0 = all) when the box has them.  Every
