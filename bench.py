@@ -43,16 +43,19 @@ def csrc_sha() -> str:
 
 def committed_traffic(kind: str, dist: int, blocks: int):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
-    from profiles/r02/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel sources and
+    from profiles/r03 (or r02)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel sources and
     this workload; otherwise None (a stale number would be a lie)."""
-    f = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    if not os.path.exists(f):
+    for rnd in ("r03", "r02"):
+        f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if os.path.exists(f) and json.load(open(f)).get("csrc_sha") == csrc_sha():
+            break
+    else:
         return None, None
     d = json.load(open(f))
     e = d.get(kind)
     if d.get("csrc_sha") != csrc_sha() or not e or e.get("dist") != dist or e.get("blocks") != blocks:
         return None, None
-    return int(e["bytes_per_launch"]), f"profiles/r02/pmc_traffic.json[{kind}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch; csrc {d['csrc_sha']})"
+    return int(e["bytes_per_launch"]), f"profiles/{rnd}/pmc_traffic.json[{kind}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch; csrc {d['csrc_sha']})"
 
 
 def parse_args():
@@ -71,7 +74,25 @@ def parse_args():
                     help="block->hardware mapping of the decoder (auto = library default)")
     ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
+    ap.add_argument("--verify-budget", type=float, default=45.0,
+                    help="seconds of host time for EACH full-corpus encoder check against the CPU reference (0 = skip)")
     return ap.parse_args()
+
+
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks (one per GPU) under torch.distributed.run
+    with the same arguments and hand its exit code back.  The driver's own launch line (python -m torch.distributed.run
+    --nproc-per-node N ... bench.py --gpus N) sets WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 @contextlib.contextmanager
@@ -136,6 +157,38 @@ class Workload:
         return self.raw_bytes + self.comp_bytes + 8 * self.n
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def full_corpus_encoder_check(torch, batch, comp, clen, hc, dist, seed, first, step, budget):
+    """EVERY block of the batch against the CPU codec: per-block (compressed length, checksum of the compressed bytes) from
+    the GPU rows vs the same two numbers from the CPU reference, which regenerates each block from its seed, compresses it
+    and keeps nothing else (oracle/batch.c lz4o_verify_stream; all host cores; stops after `budget` seconds and says how far
+    it got).  Outside every timed region.  The reference's bar: src/LZ4.Tests/ConformanceTests.cs:121-133."""
+    import numpy as np
+    from oracle.oracle import Oracle, Reference
+    o = Oracle()
+    codec = Reference() if Reference.available() else o
+    n = comp.shape[0]
+    g_sum = batch.checksum(comp, clen).cpu().numpy().view(np.uint64)
+    g_len = clen.cpu().numpy()
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    done, c_len, c_sum = o.verify_stream(codec, hc, dist, seed, first, step, n, length=batch.BLOCK, threads=cores, budget_seconds=budget)
+    dt = time.time() - t0
+    bad = np.nonzero((g_len[:done] != c_len[:done]) | (g_sum[:done] != c_sum[:done]))[0]
+    return {"blocks_compared": done, "blocks": n, "all_equal": bool(done > 0 and bad.size == 0), "mismatching_blocks": int(bad.size),
+            "first_mismatch": int(bad[0]) if bad.size else None, "cpu_seconds": round(dt, 2), "cpu_codec": codec.kind,
+            "what": "per block: compressed length and 64-bit checksum of the compressed bytes, GPU rows vs the CPU codec on the regenerated block"}
+
+
 def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
     """The CPU codec on this box's host cores, bounded sample of the same workload (same generator,
     same seed, first `sample_blocks` blocks).  Also the bench's parity spot check: the GPU's compressed
@@ -174,6 +227,10 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
     assert (hlen > 0).all()
     return {
         "value": round(sample_blocks * 65536 / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
+        "label": ("C oracle stand-in for LZ4pn: the reference's own original/lz4.c + lz4hc.c (the C the LZ4pn C# is generated from), "
+                  "built with the flags of its 64-bit native back-end" if kind == "reference" else
+                  "C oracle stand-in for LZ4pn: from-scratch C restatement (oracle/lz4_oracle.c)"),
+        "cpu_model": cpu_model(),
         "sample": f"{sample_blocks} x 64 KiB {DIST_NAMES[dist]} blocks (first blocks of the GPU batch), decode, "
                   f"best of {passes} passes, {cores} threads; encode on the same sample "
                   f"{round(sample_blocks * 65536 / t_enc / 1e9, 3)} GB/s",
@@ -185,16 +242,25 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_as_ranks(args)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} is running as {world} rank(s): launch it with --nproc-per-node {args.gpus} "
+                         f"(or without a launcher, and it starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the codec")
     # (LZ4HIP_BENCH_SHARE_GPU=1: every rank uses cuda:0 -- only for exercising the N>1 code path on a 1-GPU box)
-    torch.cuda.set_device(0 if os.environ.get("LZ4HIP_BENCH_SHARE_GPU") else local_rank)
+    share_gpu = bool(os.environ.get("LZ4HIP_BENCH_SHARE_GPU"))
+    if not share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible "
+                         f"(LZ4HIP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 to exercise the code path, not to measure)")
+    torch.cuda.set_device(0 if share_gpu else local_rank)
     if world > 1:
         # The data path has no collective (blocks are independent, sharded round-robin); ranks only meet at
         # the timing barriers and to combine three scalars, which gloo does over host memory.
@@ -225,10 +291,8 @@ def main():
         n //= 2
     # round-robin shard of a global batch of n*world blocks: local block j is global block j*world + rank
     seed = args.seed
-    if args.decoder != "auto":
-        os.environ["LZ4HIP_DECODER"] = args.decoder
-    if args.encoder != "auto":
-        os.environ["LZ4HIP_ENCODER"] = args.encoder
+    _lib.tuning_set("decoder", args.decoder)
+    _lib.tuning_set("encoder", args.encoder)
     wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world, dst_pad=args.dst_pad)
     for _ in range(max(args.warmup, 0)):
         wl.decode_step()
@@ -243,9 +307,16 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64)
     stats = torch.tensor([float(wl.algorithmic_bytes), float(wl.comp_bytes), float(ok)], dtype=torch.float64)
+    # which physical device each rank really ran on (PCI bus id): n_gpus counts ranks, distinct_devices says whether they shared
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    dev_ids = [(os.uname().nodename, str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or torch.cuda.current_device()))]
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dev_ids[0])
+        dev_ids = gathered
+    distinct_devices = len(set(dev_ids))
     elapsed = float(tmax.item())
     all_ok = int(stats[2].item()) == world
 
@@ -267,14 +338,20 @@ def main():
     hc_roof = None                                                               # BASELINE configs[3]
     if world == 1 and not args.no_extras and not args.hc_only and args.decoder == "auto":
         for name in ("lane", "wave"):
-            os.environ["LZ4HIP_DECODER"] = name
+            _lib.tuning_set("decoder", name)
             wl.back.zero_()
             wl.decode_step()
             torch.cuda.synchronize()
             t = min(event_ms(wl.decode_step, torch) for _ in range(2))
             head[f"decode_{name}_GBps"] = round(wl.raw_bytes / (t / 1e3) / 1e9, 2)
             head[f"decode_{name}_ok"] = wl.verify()
-        del os.environ["LZ4HIP_DECODER"]
+        _lib.tuning_set("decoder", "auto")
+    enc_check = hc_check = None
+    if world == 1 and not args.no_cpu and args.verify_budget > 0 and args.encoder == "auto":
+        try:
+            enc_check = full_corpus_encoder_check(torch, batch, wl.comp, wl.clen, False, args.dist, seed, 0, 1, args.verify_budget)
+        except Exception as e:
+            enc_check = {"error": repr(e)}
     if world == 1 and not args.no_extras:
         del wl
         torch.cuda.empty_cache()
@@ -289,14 +366,14 @@ def main():
             alt = {}
             if args.decoder == "auto":          # A/B: the other mapping on the same batch
                 for name in ("lane", "wave"):
-                    os.environ["LZ4HIP_DECODER"] = name
+                    _lib.tuning_set("decoder", name)
                     w.back.zero_()
                     w.decode_step()
                     torch.cuda.synchronize()
                     t = min(event_ms(w.decode_step, torch) for _ in range(2))
                     alt[f"decode_{name}_GBps"] = round(w.raw_bytes / (t / 1e3) / 1e9, 2)
                     alt[f"decode_{name}_ok"] = w.verify()
-                del os.environ["LZ4HIP_DECODER"]
+                _lib.tuning_set("decoder", "auto")
             extras[DIST_NAMES[d]] = {
                 **alt,
                 "decode_GBps": round(w.raw_bytes / (min(ms) / 1e3) / 1e9, 2),
@@ -325,6 +402,11 @@ def main():
             back = torch.empty_like(raw)
             used = batch.decode(comp, clen, back, batch.BLOCK)
             hc_roof = {"ms": ms, "alg": m * batch.BLOCK + int(clen.to(torch.int64).sum().item()) + 8 * m, "blocks": m}
+            if not args.no_cpu and args.verify_budget > 0:
+                try:
+                    hc_check = full_corpus_encoder_check(torch, batch, comp, clen, True, args.dist, seed, 0, 1, args.verify_budget)
+                except Exception as e:
+                    hc_check = {"error": repr(e)}
             extras["LZ4HC " + DIST_NAMES[args.dist]] = {
                 "encode_hc_GBps": round(m * batch.BLOCK / (ms / 1e3) / 1e9, 3),
                 "ratio": round(float(clen.double().sum().item()) / (m * batch.BLOCK), 4), "blocks": m,
@@ -408,7 +490,7 @@ def main():
     achieved = alg_bytes_local / (mean_kernel_ms / 1e3) / 1e9
     wave_mapped = args.decoder == "wave" or (args.decoder == "auto" and (head["ratio"] < 0.125 or head["ratio"] > 0.9))
 
-    def side_roofline(r, kind, kernel):
+    def side_roofline(r, kind, kernel, check=None):
         if r is None:
             return None
         a = r["alg"] / (r["ms"] / 1e3) / 1e9
@@ -416,7 +498,8 @@ def main():
         return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": r["alg"], "kernel_ms": round(r["ms"], 3), "blocks": r["blocks"],
-                "uncompressed_GBps": round(r["blocks"] * batch.BLOCK / (r["ms"] / 1e3) / 1e9, 2)}
+                "uncompressed_GBps": round(r["blocks"] * batch.BLOCK / (r["ms"] / 1e3) / 1e9, 2),
+                "bit_exact_vs_cpu_reference": check}
 
     line = {
         "metric": "uncompressed GB/s, batched 64KiB-block encode+decode: value = decode (known output size) per step over the "
@@ -430,6 +513,7 @@ def main():
                         f"({DIST_NAMES[args.dist]}, compressed on the GPU by the bit-exact fast encoder), known output size",
             "blocks_per_gpu": n, "block_bytes": batch.BLOCK, "distribution": DIST_NAMES[args.dist],
             "sharding": f"round-robin by rank, {world} rank(s), no data-path collective",
+            "ranks": world, "distinct_devices": distinct_devices,
             "frac_of_aggregate_hbm_peak": round(float(stats[0].item()) / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
         },
         "roofline": {
@@ -442,8 +526,8 @@ def main():
         },
         # BASELINE configs[2] / [3]: one launch over the batch, HIP events on the launch stream, same algorithmic bytes
         "roofline_encode": side_roofline(enc_roof, "encode_fast", "lz4hip::encode_fast_kernel (one wavefront per block, 64-probe search, hands dense blocks over) + "
-                                         "lz4hip::encode_fast_lane_kernel (LZ4_compress64kCtx, one lane per block, the blocks handed over)"),
-        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::encode_hc_lane_kernel (LZ4_compressHCCtx, one lane per block)"),
+                                         "lz4hip::encode_fast_lane_kernel (LZ4_compress64kCtx, one lane per block, the blocks handed over)", enc_check),
+        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::encode_hc_lane_kernel (LZ4_compressHCCtx, one lane per block)", hc_check),
         "cpu_baseline": cpu,
         "verified": all_ok,
         "csrc_sha": csrc_sha(),

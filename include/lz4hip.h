@@ -75,7 +75,9 @@ typedef struct lz4hip_batch {
     int64_t        dst_stride;
     const int32_t* dst_cap;      /* per-block capacity (encode, unknown-size decode) or exact size (known-size decode); NULL => dst_cap_all */
     int32_t        dst_cap_all;
-    int32_t        src_len_all;  /* length of every block when src_len == NULL; otherwise an optional upper bound on src_len[i] (0 = unknown) */
+    int32_t        src_len_all;  /* length of every block when src_len == NULL; otherwise a HINT: 0 = unknown, else it MUST be an upper
+                                    bound on every src_len[i] (LZ4HC picks its 16-bit-head kernels from "<= 65536"; a too-small
+                                    value with longer blocks is a caller error and yields LZ4HIP_E_ARGUMENT results for those blocks) */
     int32_t*       result;       /* per-block codec result, conventions above */
     int64_t        n_blocks;
 } lz4hip_batch_t;
@@ -91,7 +93,8 @@ int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
 
 /* Host-resident batches sharded over several GPUs of the node: block i is processed by the (i mod N)-th device
  * selected by device_mask (bit d = HIP device d; 0 = every visible device) -- the round-robin partition of
- * SURVEY.md 8e.  One worker thread and one staging pipeline per device, no inter-device traffic; per-block results
+ * SURVEY.md 8e.  One PERSISTENT worker thread and one staging pipeline per device (started on first use, reused by every
+ * later call; lz4hip_release_workspaces gives their memory back), no inter-device traffic; per-block results
  * and payloads land in the caller's arrays in global block order.  This is what a C# caller (HipLZ4Batch,
  * bindings/csharp) uses to spread LZ4Codec work over the 8 GPUs of a node without any launcher. */
 int lz4hip_encode_batch_host_multi(const lz4hip_batch_t* b, int mode, uint64_t device_mask);
@@ -109,8 +112,23 @@ int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_siz
 #define LZ4HIP_K_COUNT       6
 int lz4hip_dispatch_counts(uint64_t* counts, int n);
 
+/* Named integer knobs for tests, A/B runs and deployment tuning.  Every knob takes its initial value from the
+ * environment variable in brackets ONCE, when the library first looks at a knob; the launch paths never call getenv().
+ *   "decoder", "encoder", "hc"   [LZ4HIP_DECODER / _ENCODER / _HC = wave | lane]  0 automatic, 1 one wavefront per block,
+ *                                 2 one lane per block -- forces that mapping for EVERY block, whatever the batch size
+ *   "encoder_waves_per_cu", "hc_waves_per_cu"  [LZ4HIP_ENCODER_WAVES_PER_CU, LZ4HIP_HC_WAVES_PER_CU]  residency of the
+ *                                 persistent lane-per-block encoder grids (0 = built-in default)
+ *   "hc_groups"                  [LZ4HIP_HC_GROUPS]  wavefronts of the LZ4HC lane grid (0 = from the residency)
+ *   "host_threads", "host_slices" [LZ4HIP_HOST_THREADS, LZ4HIP_HOST_SLICES]  host-pointer batches: gather/scatter threads, slices per batch
+ *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
+ *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
+ * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */
+int lz4hip_tuning_set(const char* name, int value);
+int lz4hip_tuning_get(const char* name);
+
 /* Frees the grow-only kernel workspaces (encoder hash-table / LZ4HC slabs) of the CURRENT device after
- * waiting for their last user, and the calling thread's host-pointer staging (device images, pinned slots) for it.  The reference frees its tables before every return (original/lz4.c:780-786);
+ * waiting for their last user, the calling thread's host-pointer staging (device images, pinned slots) for it, and that of the *_multi entry
+ * points' persistent device workers.  The reference frees its tables before every return (original/lz4.c:780-786);
  * the library caches them between calls, this is how a caller gets the memory back. */
 int lz4hip_release_workspaces(void);
 

@@ -34,6 +34,8 @@ SYMBOLS = [
     ("lz4hip_compressBound", C.c_int, [C.c_int]),
     ("lz4hip_dispatch_counts", C.c_int, [C.c_void_p, C.c_int]),
     ("lz4hip_release_workspaces", C.c_int, []),
+    ("lz4hip_tuning_set", C.c_int, [C.c_char_p, C.c_int]),
+    ("lz4hip_tuning_get", C.c_int, [C.c_char_p]),
     ("lz4hip_compress_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("lz4hip_compress", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("lz4hip_compressHC_limitedOutput", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -84,6 +86,36 @@ def dispatch_counts() -> list:
     n = lib().lz4hip_dispatch_counts(buf, K_COUNT)
     assert n == K_COUNT
     return list(buf)
+
+
+_MAPPING = {"auto": 0, "wave": 1, "lane": 2}
+
+
+def tuning_set(name: str, value) -> int:
+    """lz4hip_tuning_set; mapping knobs also take "auto" / "wave" / "lane".  Returns the previous value."""
+    v = _MAPPING[value] if isinstance(value, str) else int(value)
+    return check(lib().lz4hip_tuning_set(name.encode(), v))
+
+
+def tuning_get(name: str) -> int:
+    return check(lib().lz4hip_tuning_get(name.encode()))
+
+
+class tuning:
+    """with tuning(decoder="lane", hc_groups=4): ...  -- sets knobs, restores the previous values on exit."""
+
+    def __init__(self, **knobs):
+        self.knobs, self.prev = knobs, {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.prev[k] = tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            tuning_set(k, v)
+        return False
 
 
 def check(rc: int) -> int:

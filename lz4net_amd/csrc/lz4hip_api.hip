@@ -16,9 +16,11 @@
 #include "../../include/lz4hip.h"
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
-#include <mutex>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +35,35 @@ thread_local std::string g_last_error;
 // mapping is known to have run it.
 std::atomic<uint64_t> g_dispatch[LZ4HIP_K_COUNT];
 void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxed); }
+
+// Named integer knobs (lz4hip_tuning_set / _get).  Each one takes its initial value from the environment ONCE, the
+// first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
+// Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
+enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobCount };
+struct KnobInfo { const char* name; const char* env; bool mapping; };
+const KnobInfo kKnobInfo[kKnobCount] = {
+    { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
+    { "encoder_waves_per_cu", "LZ4HIP_ENCODER_WAVES_PER_CU", false }, { "hc_waves_per_cu", "LZ4HIP_HC_WAVES_PER_CU", false },
+    { "hc_groups", "LZ4HIP_HC_GROUPS", false },                     // persistent grid of the LZ4HC lane kernel (tests: few lanes, many blocks each)
+    { "host_threads", "LZ4HIP_HOST_THREADS", false }, { "host_slices", "LZ4HIP_HOST_SLICES", false },
+    { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
+};
+std::atomic<int> g_knob[kKnobCount];
+std::once_flag g_knob_once;
+void knobs_init()
+{
+    std::call_once(g_knob_once, [] {
+        for (int k = 0; k < kKnobCount; k++) {
+            const char* e = getenv(kKnobInfo[k].env);
+            int v = 0;
+            if (e && kKnobInfo[k].mapping) v = e[0] == 'w' ? 1 : (e[0] == 'l' ? 2 : 0);
+            else if (e) v = atoi(e);
+            g_knob[k].store(v < 0 ? 0 : v, std::memory_order_relaxed);
+        }
+    });
+}
+int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed); }
 
 // A lone wavefront of the lane mapping needs milliseconds for its 64 blocks, so the mapping only pays once the
 // batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
@@ -170,10 +201,10 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // fill the lanes is therefore encoded by two launches: the wavefront mapping over every block, which hands a
         // block over (kDeferredResult) as soon as 16 consecutive sequences cover less than 1 KiB, then the lane mapping
         // over the blocks handed over.  Small batches use the wavefront mapping only.
-        // LZ4HIP_ENCODER=wave|lane forces ONE mapping for every block (tests, A-B runs).
-        const char* force = getenv("LZ4HIP_ENCODER");
+        // The "encoder" knob (LZ4HIP_ENCODER=wave|lane at load time, lz4hip_tuning_set) forces ONE mapping for every block.
+        const int force = knob(kKnobEncoder);
         char pick = d.n_blocks >= kLaneEncodeMinBlocks ? 'a' : 'w';  // 'a': both launches
-        if (force && (force[0] == 'w' || force[0] == 'l')) pick = force[0];
+        if (force) pick = force == 1 ? 'w' : 'l';
         Lease lease;
         void* ws = nullptr;
         int64_t groups = 0;
@@ -181,8 +212,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             int dev = 0, cus = 0;
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            int wpc = kLaneEncodeWavesPerCu;
-            if (const char* e = getenv("LZ4HIP_ENCODER_WAVES_PER_CU")) wpc = atoi(e);
+            int wpc = knob(kKnobEncoderWavesPerCu) > 0 ? knob(kKnobEncoderWavesPerCu) : kLaneEncodeWavesPerCu;
             int rc = lease_begin(g_fast_ws, stream, lease);
             if (rc) return rc;
             // the slab holds one table per resident lane; if it cannot be had, halve the residency, and
@@ -218,24 +248,24 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         const bool small = b->src_len_all > 0 && b->src_len_all <= 65536;
         // Large batches: one lane per block (lz4hip_hc_lane.hpp), state in a per-lane global slab; if the slab
         // cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
-        // LZ4HIP_HC=wave|lane overrides (A-B runs).
-        const char* force = getenv("LZ4HIP_HC");
+        // The "hc" knob (LZ4HIP_HC=wave|lane at load time, lz4hip_tuning_set) overrides.
+        const int force = knob(kKnobHc);
         // (a lane needs 1.3 - 2.4 s for its block, growing with the number of lanes in flight; the wavefront mapping does
         //  ~11 k blocks per second: measured crossover at 16 k blocks, profiles/r01/hc_small_batches.txt)
         bool lane_per_block = d.n_blocks >= 16384;
-        if (force && force[0] == 'w') lane_per_block = false;
-        if (force && force[0] == 'l') lane_per_block = true;
+        if (force == 1) lane_per_block = false;
+        if (force == 2) lane_per_block = true;
         Lease lease;
         int rc = lease_begin(g_hc_ws, stream, lease);
         if (rc) return rc;
         if (lane_per_block) {
             const size_t slab = small ? kHcLaneSlab16 : kHcLaneSlab32;
-            int wpc = kHcLaneWavesPerCu;
-            if (const char* e = getenv("LZ4HIP_HC_WAVES_PER_CU")) wpc = atoi(e);
+            int wpc = knob(kKnobHcWavesPerCu) > 0 ? knob(kKnobHcWavesPerCu) : kHcLaneWavesPerCu;
             void* ws = nullptr;
             int64_t groups = 0;
             for (; wpc >= 1; wpc /= 2) {
                 groups = (int64_t)cus * wpc;
+                if (knob(kKnobHcGroups) > 0) groups = knob(kKnobHcGroups);
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
                 if (lease_reserve(lease, (size_t)groups * 64 * slab + 256) == 0) { ws = lease.p; break; }
             }
@@ -276,31 +306,20 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     // lz4hip_decode_lane.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
     // partitioned per block by block_selected(): two launches, each skipping the other's blocks.
     // Small batches cannot fill the lanes and use the wavefront mapping only.
-    // LZ4HIP_DECODER=wave|lane forces one mapping for EVERY block, whatever the batch size (tests, A-B runs).
-    const char* force = getenv("LZ4HIP_DECODER");
+    // The "decoder" knob (LZ4HIP_DECODER=wave|lane at load time, lz4hip_tuning_set) forces one mapping for EVERY block,
+    // whatever the batch size (tests, A-B runs).
+    const int force = knob(kKnobDecoder);
     int wave_filter = kStreamingBlocks, lane_filter = kFineGrainedBlocks;
-    if (force && force[0] == 'w') { wave_filter = kAllBlocks; lane_filter = -1; }
-    else if (force && force[0] == 'l') { lane_filter = kAllBlocks; wave_filter = -1; }
+    if (force == 1) { wave_filter = kAllBlocks; lane_filter = -1; }
+    else if (force == 2) { lane_filter = kAllBlocks; wave_filter = -1; }
     else if (d.n_blocks < kLaneDecodeMinBlocks) { wave_filter = kAllBlocks; lane_filter = -1; }
     if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU).
-        // LZ4HIP_RING_BYTES / LZ4HIP_STAGE_BYTES / LZ4HIP_LANE_LDS_PAD: tuning runs (profiles/r02/decoder_ab_*.txt).
-        int ring = kLaneDecodeRingBytes, stage = kLaneDecodeStageBytes;
-        unsigned pad = 0;
-        if (const char* e = getenv("LZ4HIP_RING_BYTES")) ring = atoi(e);
-        if (const char* e = getenv("LZ4HIP_STAGE_BYTES")) stage = atoi(e);
-        if (const char* e = getenv("LZ4HIP_LANE_LDS_PAD")) pad = (unsigned)atoi(e);
-#define LZ4HIP_LAUNCH_LANE(R, SB)                                                                                               \
-        do {                                                                                                                    \
-            if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), pad, stream, d, lane_filter);   \
-            else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), pad, stream, d, lane_filter);  \
-        } while (0)
-        if (ring == 128 && stage == 128) LZ4HIP_LAUNCH_LANE(128, 128);
-        else if (ring == 256 && stage == 128) LZ4HIP_LAUNCH_LANE(256, 128);
-        else if (ring == 256) LZ4HIP_LAUNCH_LANE(256, 64);
-        else LZ4HIP_LAUNCH_LANE(128, 64);
-#undef LZ4HIP_LAUNCH_LANE
+        // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU; the
+        // other ring / staging sizes that were measured are in profiles/r02/decoder_ab_*.txt).
+        constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
+        if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+        else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
         count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {
@@ -368,13 +387,82 @@ struct HostContext {
     Pinned pin_in[kHostSlots], pin_out[kHostSlots];
     HostPipe pipe;
 };
-HostContext* host_context(int dev)
+// One per (thread, device), created on first use and kept for the life of the thread.  The threads that call this are
+// the callers' own (single-device entry points) and the library's PERSISTENT device workers (multi-device entry points,
+// below) -- never a thread the library starts per call.
+HostContext* host_context(int dev, bool create = true)
 {
     static thread_local HostContext* ctx[64] = {};
     if (dev < 0 || dev >= 64) return nullptr;
-    if (!ctx[dev]) ctx[dev] = new HostContext();   // lives as long as the thread (see ~Scratch)
+    if (!ctx[dev] && create) ctx[dev] = new HostContext();   // lives as long as the thread (see ~Scratch)
     return ctx[dev];
 }
+void release_host_context(int dev)
+{
+    if (HostContext* hc = host_context(dev, false)) {
+        hc->scratch.release();
+        for (int k = 0; k < kHostSlots; k++) { hc->pin_in[k].release(); hc->pin_out[k].release(); }
+    }
+}
+
+// ---- persistent device workers of the multi-device entry points --------------------------------------------------------
+// One thread per (logical) device, started on first use and kept until the process ends: its staging context (device
+// images, pinned slots, streams, events) is allocated once and reused by every later call.  A caller posts one job per
+// worker and waits for all of them; concurrent callers queue on the worker's `busy` mutex (taken in ascending worker order).
+struct DeviceWorker {
+    std::mutex busy;                 // held by the caller that owns the worker for one job
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, finished = false, started = false;
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return has_job; });
+                j = std::move(job); has_job = false;
+            }
+            j();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                finished = true;
+            }
+            cv.notify_all();
+        }
+    }
+    // (caller holds `busy`)
+    int post(std::function<void()> j)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            try { std::thread(&DeviceWorker::loop, this).detach(); }
+            catch (const std::system_error& e) { return fail(LZ4HIP_E_MEMORY, std::string("cannot start a device worker thread: ") + e.what()); }
+            started = true;
+        }
+        job = std::move(j); has_job = true; finished = false;
+        lk.unlock();
+        cv.notify_all();
+        return 0;
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return finished; });
+    }
+};
+constexpr int kMaxWorkers = 64;
+DeviceWorker* g_worker[kMaxWorkers];         // never freed: a worker blocked in cv.wait at process exit must keep its object
+std::mutex g_worker_mu;
+DeviceWorker* device_worker(int logical)
+{
+    std::lock_guard<std::mutex> lk(g_worker_mu);
+    if (!g_worker[logical]) g_worker[logical] = new DeviceWorker();
+    return g_worker[logical];
+}
+
+thread_local unsigned g_row_thread_share = 1;
 
 // f(i) for i in [0, n): on the calling thread for small jobs, on up to 16 threads (LZ4HIP_HOST_THREADS) for large ones (row gathers and
 // scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
@@ -382,15 +470,20 @@ template <class F>
 void for_rows(int64_t n, size_t bytes, F f)
 {
     unsigned t = std::thread::hardware_concurrency();
-    static const unsigned cap = [] { const char* e = getenv("LZ4HIP_HOST_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
+    unsigned cap = knob(kKnobHostThreads) > 0 ? (unsigned)knob(kKnobHostThreads) : 16u;
+    cap = cap / g_row_thread_share;                                  // the device workers of a multi-device call share the budget
     t = t > cap ? cap : t;
     if (bytes < (8u << 20) || n < 2 || t < 2) { for (int64_t i = 0; i < n; i++) f(i); return; }
     if ((int64_t)t > n) t = (unsigned)n;
     std::vector<std::thread> pool;
+    int64_t started_to = 0;
     for (unsigned k = 0; k < t; k++) {
         const int64_t lo = n * k / t, hi = n * (k + 1) / t;
-        pool.emplace_back([=] { for (int64_t i = lo; i < hi; i++) f(i); });
+        try { pool.emplace_back([=] { for (int64_t i = lo; i < hi; i++) f(i); }); }
+        catch (const std::system_error&) { break; }                  // no more threads to be had: the caller does the rest
+        started_to = hi;
     }
+    for (int64_t i = started_to; i < n; i++) f(i);
     for (auto& th : pool) th.join();
 }
 
@@ -422,7 +515,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     // slice size: a small batch goes in one piece; a large one in about 6 slices (LZ4HIP_HOST_SLICES; profiles/r02/host_slices_sweep.txt) of 32 MiB .. 512 MiB
     // of rows each
     const size_t row_bytes = s_stride + d_stride;
-    static const int want_slices = [] { const char* e = getenv("LZ4HIP_HOST_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 6; }();
+    const int want_slices = knob(kKnobHostSlices) > 0 ? knob(kKnobHostSlices) : 6;
     int64_t per_slice = (n + want_slices - 1) / want_slices;
     const int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
     per_slice = per_slice < lo ? lo : per_slice;
@@ -536,8 +629,10 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 
 // Host-resident batch sharded over the devices of `device_mask` (bit d = HIP device d; 0 = every visible device):
 // block i belongs to the (i mod N)-th selected device -- the partition of SURVEY.md 8e / BASELINE configs[4] -- one
-// worker thread per device, each with its own staging pipeline (run_host_batch on that device); no device ever sees
-// another device's blocks and nothing is exchanged between them.  Results land in the caller's arrays in global order.
+// persistent worker thread per device, each with its own staging pipeline (run_host_batch on that device); no device ever
+// sees another device's blocks and nothing is exchanged between them.  Results land in the caller's arrays in global order.
+// (The "logical_devices" knob makes N workers out of fewer devices, wrapping around: how the threaded path is tested on
+// a one-GPU box.)
 template <class Run>
 int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run)
 {
@@ -549,11 +644,15 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
     for (int d = 0; d < visible && d < 64; d++)
         if (device_mask == 0 || ((device_mask >> d) & 1ull)) devs.push_back(d);
     if (devs.empty()) return fail(LZ4HIP_E_ARGUMENT, "device_mask selects no visible device");
+    const int logical = knob(kKnobLogicalDevices);
+    if (logical > 0) {
+        const std::vector<int> base = devs;
+        devs.clear();
+        for (int k = 0; k < logical && k < kMaxWorkers; k++) devs.push_back(base[(size_t)k % base.size()]);
+    }
     const int64_t n = hb->n_blocks;
     if (n == 0) return 0;
     const int nd = (int)devs.size();
-    int prev_dev = 0;
-    HIP_TRY(hipGetDevice(&prev_dev));
 
     struct Shard {
         std::vector<int64_t> src_off, dst_off;
@@ -580,21 +679,36 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
         sh.b.src_len = sh.src_len.data(); sh.b.dst_cap = sh.dst_cap.data();
         sh.b.result = sh.result.data(); sh.b.n_blocks = cnt;
     }
-    auto work = [&](int k) {
-        Shard& sh = shards[(size_t)k];
-        if (sh.b.n_blocks == 0) return;
-        if (hipSetDevice(devs[(size_t)k]) != hipSuccess) { sh.rc = LZ4HIP_E_DEVICE; sh.err = "hipSetDevice failed"; return; }
-        sh.rc = run_host_batch(&sh.b, dst_len_is_result, run);
-        if (sh.rc) sh.err = g_last_error;                            // thread-local: carry it back to the caller
-    };
-    if (nd == 1) {
-        work(0);
+    if (nd == 1) {                                                   // one device: on the calling thread, with its own context
+        int prev_dev = 0;
+        HIP_TRY(hipGetDevice(&prev_dev));
+        HIP_TRY(hipSetDevice(devs[0]));
+        rc = run_host_batch(&shards[0].b, dst_len_is_result, run);
+        (void)hipSetDevice(prev_dev);
+        if (rc) return rc;
     } else {
-        std::vector<std::thread> pool;
-        for (int k = 0; k < nd; k++) pool.emplace_back(work, k);
-        for (auto& t : pool) t.join();
+        std::vector<DeviceWorker*> workers((size_t)nd);
+        for (int k = 0; k < nd; k++) workers[(size_t)k] = device_worker(k);
+        int posted = 0, post_rc = 0;
+        for (int k = 0; k < nd; k++) {                               // ascending order: concurrent callers cannot deadlock
+            DeviceWorker* w = workers[(size_t)k];
+            w->busy.lock();
+            Shard* sh = &shards[(size_t)k];
+            const int phys = devs[(size_t)k];
+            const unsigned share = (unsigned)nd;
+            post_rc = w->post([sh, phys, share, dst_len_is_result, run] {
+                if (sh->b.n_blocks == 0) return;
+                if (hipSetDevice(phys) != hipSuccess) { sh->rc = LZ4HIP_E_DEVICE; sh->err = "hipSetDevice failed"; return; }
+                g_row_thread_share = share;
+                sh->rc = run_host_batch(&sh->b, dst_len_is_result, run);
+                if (sh->rc) sh->err = g_last_error;                  // thread-local: carry it back to the caller
+            });
+            if (post_rc) { w->busy.unlock(); break; }
+            posted++;
+        }
+        for (int k = 0; k < posted; k++) { workers[(size_t)k]->wait(); workers[(size_t)k]->busy.unlock(); }
+        if (post_rc) return post_rc;
     }
-    (void)hipSetDevice(prev_dev);
     for (int k = 0; k < nd; k++) {
         const Shard& sh = shards[(size_t)k];
         if (sh.rc) return fail(sh.rc, "device " + std::to_string(devs[(size_t)k]) + ": " + sh.err);
@@ -686,11 +800,36 @@ int lz4hip_release_workspaces(void)
     }
     // ... and the CALLING thread's host-pointer staging for this device (device images + pinned slots; the host-pointer
     // entry points are synchronous, so nothing of this thread's is in flight here)
-    if (HostContext* hc = host_context(dev)) {
-        hc->scratch.release();
-        for (int k = 0; k < kHostSlots; k++) { hc->pin_in[k].release(); hc->pin_out[k].release(); }
+    release_host_context(dev);
+    // ... and that of the multi-device entry points' persistent workers for this device
+    for (int k = 0; k < kMaxWorkers; k++) {
+        DeviceWorker* w = nullptr;
+        { std::lock_guard<std::mutex> lk(g_worker_mu); w = g_worker[k]; }
+        if (!w) continue;
+        std::lock_guard<std::mutex> own(w->busy);
+        if (w->post([dev] { if (hipSetDevice(dev) == hipSuccess) release_host_context(dev); })) continue;
+        w->wait();
     }
     return 0;
+}
+
+int lz4hip_tuning_set(const char* name, int value)
+{
+    knobs_init();
+    for (int k = 0; name && k < kKnobCount; k++)
+        if (strcmp(name, kKnobInfo[k].name) == 0) {
+            if (value < 0 || (kKnobInfo[k].mapping && value > 2)) return fail(LZ4HIP_E_ARGUMENT, std::string("bad value for knob ") + name);
+            return g_knob[k].exchange(value, std::memory_order_relaxed);
+        }
+    return fail(LZ4HIP_E_ARGUMENT, std::string("unknown knob ") + (name ? name : "(null)"));
+}
+
+int lz4hip_tuning_get(const char* name)
+{
+    knobs_init();
+    for (int k = 0; name && k < kKnobCount; k++)
+        if (strcmp(name, kKnobInfo[k].name) == 0) return g_knob[k].load(std::memory_order_relaxed);
+    return fail(LZ4HIP_E_ARGUMENT, std::string("unknown knob ") + (name ? name : "(null)"));
 }
 
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream)

@@ -232,11 +232,13 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         const int match_end = lit_end + ml;
 
         // ---- materialise the sequence ----
-        if (short_lit && ll + ml <= 64) {
+        // (offset 0 -- only in corrupt streams; the match bytes keep what dst holds, like the reference's copy from itself --
+        //  takes the long path: it writes nothing to the ring and moves ring_from past the bytes the ring does not have)
+        if (short_lit && ll + ml <= 64 && off != 0) {
             const int j = lane - ll;                         // index inside the match (valid when 0 <= j < ml)
-            const bool in_match = j >= 0 && j < ml && off != 0;
+            const bool in_match = j >= 0 && j < ml;
             int jj = j < 0 ? 0 : j;
-            if (off < ml && off != 0) jj = jj % off;        // byte-wise overlap semantics
+            if (off < ml) jj = jj % off;                     // byte-wise overlap semantics
             const int sidx = ref + jj;                       // source index in dst
             const int from_lit = sidx - op;                  // >= 0: the byte is one of THIS sequence's literals
             const uint32_t via_lit = wv::shuffle(lit_byte, from_lit < 0 ? 0 : from_lit);

@@ -128,6 +128,21 @@ class Oracle(_Codec):
         lib.lz4o_batch_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
 
+        lib.lz4o_verify_stream.restype = C.c_int64
+        lib.lz4o_verify_stream.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+
+    # -- full-corpus encoder check (nothing but lengths and checksums is kept) ----------------
+    def verify_stream(self, codec: "_Codec", hc: bool, dist: int, seed: int, first: int, step: int, n: int,
+                      length: int = 65536, threads: int = 1, budget_seconds: float = 0.0):
+        """For synthetic blocks first + i*step, i < n: regenerate, compress with `codec`, checksum the compressed bytes.
+        Returns (done, lens[int32], sums[uint64]); blocks [0, done) were processed (all of them unless the time budget ran out)."""
+        lens = np.zeros(n, np.int32)
+        sums = np.zeros(n, np.uint64)
+        done = self.lib.lz4o_verify_stream(codec.fn_ptr("hc" if hc else "enc"), dist, seed, first, step, n, length,
+                                           compress_bound(length), lens.ctypes.data, sums.ctypes.data, threads, budget_seconds)
+        return int(done), lens, sums
+
     # -- synthetic data (CPU twin of the device generators) ----------------------------------
     def gen(self, dist: int, seed: int, first_block: int, n: int, length: int = 65536,
             stride: int | None = None) -> np.ndarray:

@@ -26,8 +26,9 @@ def reference():
     return Reference()
 
 
-# ---- forcing a block->hardware mapping AND proving that it ran (lz4hip_dispatch_counts) ------------------------
+# ---- forcing a block->hardware mapping (lz4hip_tuning_set) AND proving that it ran (lz4hip_dispatch_counts) --------
 _FAMILY = {"LZ4HIP_DECODER": (0, 1), "LZ4HIP_ENCODER": (2, 3), "LZ4HIP_HC": (4, 5)}   # (wave counter, lane counter)
+_KNOB = {"LZ4HIP_DECODER": "decoder", "LZ4HIP_ENCODER": "encoder", "LZ4HIP_HC": "hc"}
 
 
 class ForcedMapping:
@@ -39,13 +40,13 @@ class ForcedMapping:
 
     def __enter__(self):
         from lz4net_amd import _lib
-        os.environ[self.var] = self.which
+        self.prev = _lib.tuning_set(_KNOB[self.var], self.which)
         self.before = _lib.dispatch_counts()
         return self
 
     def __exit__(self, exc_type, exc, tb):
         from lz4net_amd import _lib
-        os.environ.pop(self.var, None)
+        _lib.tuning_set(_KNOB[self.var], self.prev)
         if exc_type is not None:
             return False
         after = _lib.dispatch_counts()

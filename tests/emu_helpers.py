@@ -92,6 +92,18 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
     return res, dst
 
 
+def encode_hc_lane_static(blocks):
+    """LZ4HC lane kernel's per-block function with STATIC assignment: lane L encodes blocks L, L+64, L+128, ... in order on
+    one slab (slab-reuse test)."""
+    src, sl = pack(blocks)
+    caps = np.array([len(b) + len(b) // 255 + 16 for b in blocks], np.int32)
+    ds = max(int(caps.max()), 1) + 64
+    dst = np.full((len(blocks), ds), 0xA5, np.uint8)
+    res = np.zeros(len(blocks), np.int32)
+    lib().emu_encode_hc_lane_static(_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
+    return res, dst
+
+
 def encode_two_launches(blocks, caps=None):
     """launch_encode's default for large batches: wavefront-per-block launch with the hand-over rule, then the lane-per-block
     launch over the blocks handed over.  Returns (result, dst, deferred flags)."""

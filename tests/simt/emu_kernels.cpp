@@ -126,6 +126,32 @@ void emu_encode_hc_lane(const uint8_t* src, int64_t src_stride, const int32_t* s
 }
 #endif
 
+#ifdef LZ4HIP_HAVE_HC
+// Slab reuse of the LZ4HC lane kernel, deterministically: lane L of the single wavefront encodes blocks L, L + 64, L + 128, ...
+// IN THAT ORDER on its own slab (the product kernel hands blocks out through an atomic counter, so which lane gets which
+// block is not reproducible; the per-block function and the slab are the product's).
+static void hc_lane_static_kernel(Batch b, uint8_t* slabs, unsigned long long slab_bytes)
+{
+    uint8_t* slab = slabs + (size_t)threadIdx.x * (size_t)slab_bytes;
+    for (int64_t blk = threadIdx.x; blk < b.n_blocks; blk += 64) {
+        const int n = batch_src_len(b, blk), cap = batch_dst_cap(b, blk);
+        int r;
+        if (n <= 65536) r = lane_encode_hc_block<uint16_t>(batch_src(b, blk), n, batch_dst(b, blk), cap, slab);
+        else            r = lane_encode_hc_block<uint32_t>(batch_src(b, blk), n, batch_dst(b, blk), cap, slab);
+        b.result[blk] = r;
+    }
+}
+void emu_encode_hc_lane_static(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                               int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static std::vector<uint8_t> ws;
+    ws.assign((size_t)64 * kHcLaneSlab32, 0x5A);                    // poisoned once; afterwards whatever the previous block left
+    uint8_t* slabs = ws.data();
+    simt::launch(dim3(1), dim3(64), 0, [=] { hc_lane_static_kernel(b, slabs, (unsigned long long)kHcLaneSlab32); });
+}
+#endif
+
 void emu_synth(int dist, uint64_t seed, uint64_t first_block, uint64_t block_step, int64_t n, uint8_t* out, int64_t stride, int len)
 {
     SynthArgs a = { out, stride, n, seed, first_block, block_step, len, dist };

@@ -64,10 +64,85 @@ def make_stream(rng, target, tail_kind=0):
     return np.frombuffer(comp, dtype=np.uint8).copy(), (np.frombuffer(bytes(raw), dtype=np.uint8).copy() if tail_kind == 0 else None)
 
 
+def make_zero_offset_stream(rng):
+    """A match with offset 0 (its bytes keep whatever the destination holds) directly followed by SHORT sequences whose
+    matches read those very bytes back -- the case in which a decoder that mirrors its recent output somewhere (LDS ring)
+    must not serve stale mirror bytes.  Returns (stream, output size); the oracle defines the expected bytes."""
+    out = bytearray()
+    size = 0
+
+    def seq(ll, ml, off):
+        nonlocal size
+        out.append((min(ll, 15) << 4) | min(ml - 4, 15))
+        if ll >= 15:
+            _put_len(out, ll - 15)
+        out.extend(rng.integers(0, 256, ll, dtype=np.uint8).tobytes())
+        out.extend(bytes([off & 255, off >> 8]))
+        if ml - 4 >= 15:
+            _put_len(out, ml - 4 - 15)
+        size += ll + ml
+
+    seq(int(rng.integers(1, 30)), int(rng.integers(4, 19)), 1 + int(rng.integers(0, 1)))       # something before
+    for _ in range(int(rng.integers(1, 4))):
+        ml0 = int(rng.integers(4, 40))
+        seq(int(rng.integers(0, 3)), ml0, 0)                                                   # offset 0
+        for _ in range(int(rng.integers(1, 4))):                                               # short matches into its bytes
+            ll = int(rng.integers(0, 3))
+            seq(ll, int(rng.integers(4, 19)), int(rng.integers(1, ml0 + ll + 1)))
+    run = 12 + int(rng.integers(0, 20))
+    out.append(min(run, 15) << 4)
+    if run >= 15:
+        _put_len(out, run - 15)
+    out.extend(rng.integers(0, 256, run, dtype=np.uint8).tobytes())
+    size += run
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy(), size
+
+
+def is_zero_offset_case(i):
+    return i % 10 == 9
+
+
+def has_zero_offset(c, limit):
+    """Does a decoder walking stream `c` (stopping once `limit` output bytes are reached or the stream ends) meet a match
+    with offset 0?  For such streams only the return codes are compared with the REFERENCE: the bytes of an offset-0 match
+    are whatever the destination held, which in the reference includes the overshoot of its own 8-byte wild copies -- an
+    artefact, not a result.  The kernels are compared with the oracle (exact-length copies: a hole keeps the caller's
+    bytes), bytes included."""
+    c = bytes(c)
+    ip = op = 0
+    n = len(c)
+    while ip < n and op <= limit:
+        tok = c[ip]; ip += 1
+        ll = tok >> 4
+        if ll == 15:
+            while ip < n:
+                b = c[ip]; ip += 1; ll += b
+                if b != 255:
+                    break
+        ip += ll; op += ll
+        if ip + 2 > n or op >= limit:
+            return False
+        if c[ip] == 0 and c[ip + 1] == 0:
+            return True
+        ip += 2
+        ml = tok & 15
+        if ml == 15:
+            while ip < n:
+                b = c[ip]; ip += 1; ml += b
+                if b != 255:
+                    break
+        op += ml + 4
+    return False
+
+
 def cases(seed, count, max_size=6000):
     rng = np.random.default_rng(seed)
     out = []
     for i in range(count):
+        if is_zero_offset_case(i):
+            c, size = make_zero_offset_stream(rng)
+            out.append(((c, None), size))
+            continue
         target = int(rng.choice([13, 14, 20, 64, 65, 200, 1000, 3000, max_size])) + int(rng.integers(0, 50))
         out.append((make_stream(rng, target, tail_kind=0 if i % 3 else int(rng.integers(0, 5))), target))
     return out

@@ -116,3 +116,26 @@ def test_framing_host_logic_properties():
             want.append((len(frame), n))
             frame += bytes(rnd.randrange(256) for _ in range(n))
         assert lf.parse_frame(frame) == want
+
+
+def test_tuning_knobs_without_gpu():
+    """lz4hip_tuning_set / _get are host logic: named integer knobs, previous value returned, bad names and values refused.
+    (The launch paths read these atomics and never call getenv(); the environment only seeds them, once.)"""
+    from lz4net_amd import _lib
+    L = _lib.lib()
+    for name in ("decoder", "encoder", "hc"):
+        prev = _lib.tuning_set(name, "lane")
+        assert _lib.tuning_get(name) == 2
+        assert _lib.tuning_set(name, "wave") == 2
+        assert _lib.tuning_set(name, prev) == 1
+        assert L.lz4hip_tuning_set(name.encode(), 3) == _lib.E_ARGUMENT
+    for name in ("encoder_waves_per_cu", "hc_waves_per_cu", "hc_groups", "host_threads", "host_slices", "logical_devices"):
+        prev = _lib.tuning_set(name, 5)
+        assert _lib.tuning_get(name) == 5
+        assert _lib.tuning_set(name, prev) == 5
+        assert L.lz4hip_tuning_set(name.encode(), -1) == _lib.E_ARGUMENT
+    assert L.lz4hip_tuning_set(b"no_such_knob", 1) == _lib.E_ARGUMENT and b"no_such_knob" in L.lz4hip_last_error()
+    assert L.lz4hip_tuning_get(None) == _lib.E_ARGUMENT
+    with _lib.tuning(decoder="lane", hc_groups=4):
+        assert _lib.tuning_get("decoder") == 2 and _lib.tuning_get("hc_groups") == 4
+    assert _lib.tuning_get("decoder") == 0 and _lib.tuning_get("hc_groups") == 0

@@ -80,6 +80,49 @@ def test_full_size_decode_properties(torch_cuda, oracle):
     for i in (0, 1, n // 2, n - 1):
         want = oracle.compress(oracle.gen(2, 7, i, 1)[0])
         assert lens[i] == len(want) and np.array_equal(comp[i, :len(want)].cpu().numpy(), want), i
+    _compare_whole_corpus(oracle, batch, comp, clen, False, 2, 7)
+
+
+def _compare_whole_corpus(oracle, batch, comp, clen, hc, dist, seed, budget=240.0):
+    """EVERY block's (compressed length, checksum of the compressed bytes) from the GPU rows against the CPU codec, which
+    regenerates the block from its seed, compresses it and keeps only those two numbers (oracle/batch.c
+    lz4o_verify_stream, all host cores) -- the reference's own bar is identity over the whole corpus
+    (src/LZ4.Tests/ConformanceTests.cs:121-133).  First / last 64 blocks and every 4096-th are compared byte for byte
+    as well."""
+    import os
+    from oracle.oracle import Reference
+    codec = Reference() if Reference.available() else oracle
+    n = comp.shape[0]
+    g_sum = batch.checksum(comp, clen).cpu().numpy().view(np.uint64)
+    g_len = clen.cpu().numpy()
+    done, c_len, c_sum = oracle.verify_stream(codec, hc, dist, seed, 0, 1, n, threads=os.cpu_count() or 1, budget_seconds=budget)
+    assert done >= min(n, 4096), ("the CPU side got through too few blocks to call this a corpus check", done)
+    bad = np.nonzero((g_len[:done] != c_len[:done]) | (g_sum[:done] != c_sum[:done]))[0]
+    assert bad.size == 0, (hc, "blocks differing from the CPU codec", bad[:8], "of", done)
+    print(f"whole-corpus check hc={hc}: {done} of {n} blocks identical to the CPU {codec.kind}")
+    for i in sorted(set(list(range(0, min(64, n))) + list(range(max(n - 64, 0), n)) + list(range(0, n, 4096)))):
+        want = codec.compress(oracle.gen(dist, seed, i, 1)[0], hc=hc)
+        assert g_len[i] == len(want) and np.array_equal(comp[i, :len(want)].cpu().numpy(), want), (hc, i)
+
+
+def test_full_size_hc_encode_whole_corpus(torch_cuda, oracle):
+    """BASELINE configs[3] shape (2^18 x 64 KiB, LZ4HC): every block's compressed bytes equal the CPU codec's
+    (length + checksum for all of them, bytes for the sample), and the batch round-trips."""
+    torch = torch_cuda
+    from lz4net_amd import batch
+    free, _ = torch.cuda.mem_get_info()
+    n = 1 << 18
+    while n * (2 * batch.BLOCK + batch.BOUND_STRIDE + 200000) * 1.05 > free and n > 1024:
+        n //= 2
+    raw = batch.synth(2, 11, 0, n)
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)
+    assert bool((clen > 0).all())
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen, back, batch.BLOCK)
+    assert bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    del back
+    _compare_whole_corpus(oracle, batch, comp, clen, True, 2, 11)
 
 
 def test_round_robin_sharding_single_process(torch_cuda, oracle):
@@ -133,17 +176,16 @@ def test_concurrent_streams_share_the_workspace_safely(torch_cuda, oracle):
     assert not errors, errors
 
 
-def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle, monkeypatch):
+def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle):
     """Lane encoder with one wavefront per CU and 2^20 small blocks: every lane encodes ~64 blocks in a row, so its
     epoch-stamped table wraps at least once; sampled blocks must be the oracle's bytes and all must round-trip."""
     torch = torch_cuda
-    from lz4net_amd import batch
-    monkeypatch.setenv("LZ4HIP_ENCODER_WAVES_PER_CU", "1")
+    from lz4net_amd import batch, _lib
     n, length = 1 << 20, 256
     bound = length + length // 255 + 16
     raw = batch.synth(2, 31, 0, n, length=length)
     comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
-    with ForcedMapping("LZ4HIP_ENCODER", "lane"):
+    with ForcedMapping("LZ4HIP_ENCODER", "lane"), _lib.tuning(encoder_waves_per_cu=1):
         clen = batch.encode(raw, length, comp, bound)
     back = torch.empty_like(raw)
     used = batch.decode(comp, clen, back, length)

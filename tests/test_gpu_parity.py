@@ -431,3 +431,88 @@ def test_multi_device_host_batches(gpu, oracle):
     resb = np.zeros(len(want), np.int32)
     b = gpu._batch(src, sl, dstb, caps, resb)
     assert _lib.lib().lz4hip_decode_batch_host_multi(C.byref(b), 1, 1 << 63) == _lib.E_ARGUMENT
+
+
+def _rss_kib():
+    for ln in open("/proc/self/status"):
+        if ln.startswith("VmRSS:"):
+            return int(ln.split()[1])
+    return 0
+
+
+def test_multi_device_threaded_path_does_not_leak(gpu, oracle):
+    """The threaded path of lz4hip_*_batch_host_multi (N >= 2 device workers) on whatever devices the box has: the
+    "logical_devices" knob runs 3 workers over the visible devices (wrapping around), each with its own staging context.
+    The workers are persistent, so 20 calls in a row must leave the free device memory and the process' resident set where
+    the second call left them (round 2 started fresh threads per call and abandoned one staging set per device per call:
+    device images + 8 pinned buffers + 6 streams + 13 events)."""
+    import torch
+    from lz4net_amd import _lib
+    blocks = [oracle.gen(2, 9, i, 1)[0] for i in range(96)] + [oracle.gen(3, 9, i, 1, 3000 + 41 * i)[0] for i in range(27)]
+    want = [oracle.compress(a) for a in blocks]
+    sizes = [a.size for a in blocks]
+    with _lib.tuning(logical_devices=3):
+        def one_round():
+            res, dst = gpu.encode(blocks, device_mask=0)
+            for i, w in enumerate(want):
+                assert res[i] == len(w) and np.array_equal(dst[i, :res[i]], w), i
+            used, back = gpu.decode(want, sizes, known=True, device_mask=0)
+            for i, a in enumerate(blocks):
+                assert used[i] == len(want[i]) and np.array_equal(back[i, :a.size], a), i
+        one_round()
+        one_round()
+        torch.cuda.synchronize()
+        free0, rss0 = torch.cuda.mem_get_info()[0], _rss_kib()
+        for _ in range(20):
+            one_round()
+        torch.cuda.synchronize()
+        free1, rss1 = torch.cuda.mem_get_info()[0], _rss_kib()
+        # one abandoned staging set of this batch is > 16 MiB of device memory and > 16 MiB of pinned host memory
+        assert free0 - free1 < (8 << 20), ("device memory shrank", free0 - free1)
+        assert rss1 - rss0 < (64 << 10), ("resident set grew (KiB)", rss1 - rss0)
+        # the workers' staging is given back on request, and they work again afterwards
+        before = torch.cuda.mem_get_info()[0]
+        _lib.check(_lib.lib().lz4hip_release_workspaces())
+        assert torch.cuda.mem_get_info()[0] > before
+        one_round()
+        # several caller threads at once share the workers (queueing on them), results stay per caller
+        import threading
+        errors = []
+
+        def caller():
+            try:
+                one_round()
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+        ts = [threading.Thread(target=caller) for _ in range(3)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    _lib.check(_lib.lib().lz4hip_release_workspaces())
+
+
+def test_hc_lane_slab_reuse(gpu, oracle):
+    """LZ4HC lane kernel with ONE wavefront in the grid ("hc_groups" = 1): its 64 lanes encode 320 blocks, five each on
+    average, on slabs that are never re-initialised beyond the heads and chain[0] -- blocks of 64 KiB, 70 000 bytes
+    (32-bit heads, a different slab layout) and 300 .. 30 000 bytes in random order, fuzzer-style and record-like, some
+    with long repeats.  EVERY block is compared with the oracle."""
+    from lz4net_amd import _lib
+    rng = np.random.default_rng(43)
+    blocks = []
+    for i in range(320):
+        k = int(rng.integers(0, 10))
+        sz = 65536 if k < 2 else 70000 if k == 2 else 65536 - int(rng.integers(1, 2000)) if k == 3 else int(rng.integers(300, 30000))
+        row = oracle.gen(2 if i % 3 else 3, 61, i, (sz + 65535) // 65536).reshape(-1)[:sz].copy()
+        if i % 6 == 0:
+            row[sz // 2:] = row[:sz - sz // 2]
+        if i % 11 == 0:
+            row[: sz // 4] = 9
+        blocks.append(row)
+    with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1):
+        res, dst = gpu.encode(blocks, hc=True)
+    for i, a in enumerate(blocks):
+        w = oracle.compress(a, hc=True)
+        assert res[i] == len(w), (i, a.size, res[i], len(w))
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size)

@@ -97,7 +97,8 @@ def test_decoders_identical_on_arbitrary_streams(oracle, reference):
             d1, o1 = reference.uncompress_raw(c, t)
             d2, o2 = oracle.uncompress_raw(c, t)
             assert d1 == d2, ("known", seed, i, d1, d2)
-            if d1 >= 0:
+            holes = stream_fuzz.has_zero_offset(c, t + 3)    # bytes of offset-0 matches: unspecified in the reference (see stream_fuzz)
+            if d1 >= 0 and not holes:
                 assert np.array_equal(o1[:t], o2[:t]), ("known bytes", seed, i)
             if raw is not None:
                 assert d1 == len(c) and np.array_equal(o1[:t], raw), ("well formed", seed, i)
@@ -105,5 +106,5 @@ def test_decoders_identical_on_arbitrary_streams(oracle, reference):
                 u1, p1 = reference.uncompress_unknown_raw(c, len(c), cap)
                 u2, p2 = oracle.uncompress_unknown_raw(c, len(c), cap)
                 assert u1 == u2, ("unknown", seed, i, cap, u1, u2)
-                if u1 >= 0:
+                if u1 >= 0 and not holes:
                     assert np.array_equal(p1[:u1], p2[:u1]), ("unknown bytes", seed, i, cap)

@@ -88,3 +88,49 @@ def test_two_ranks_run_the_codec_and_gather(oracle):
         block = oracle.gen(2, 4242, i, 1)[0]
         assert lens[i] == len(oracle.compress(block)), i
         assert sums[i] == (oracle.checksum(block) & 0x7FFFFFFF), i
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with N > 1 and no launcher re-executes itself under torch.distributed.run with
+    --nproc-per-node N on 127.0.0.1 and the same arguments; under a launcher (WORLD_SIZE set) it does not, and a world
+    size that differs from --gpus is refused instead of silently benchmarking one GPU."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    # under a launcher with the wrong world size: refused
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not calls and "--gpus 4" in str(e.value.code) and "1 rank" in str(e.value.code)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher():
+    """On the GPU box: `LZ4HIP_BENCH_SHARE_GPU=1 python bench.py --gpus 2` (no launcher) runs two ranks -- both on cuda:0 when
+    the box has one GPU -- and prints ONE JSON line with n_gpus 2, the round-robin shards verified on both ranks."""
+    import json
+    import subprocess
+    env = dict(os.environ, LZ4HIP_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "32768", "--steps", "2",
+                        "--warmup", "1", "--no-extras", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["config"]["ranks"] == 2
+    assert d["config"]["distinct_devices"] in (1, 2)
+    assert d["config"]["blocks_per_gpu"] == 32768 and d["value"] > 0

@@ -202,6 +202,38 @@ def test_encode_hc_limited_output(oracle, lane):
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
+def test_encode_hc_lane_slab_reuse(oracle):
+    """The LZ4HC lane kernel re-zeroes its heads per block, sets chain[0] and leaves the rest of the previous block's chain
+    (and, after a block > 64 KiB, its 32-bit heads where the 16-bit layout has its chain) in place, relying on every slot
+    being written before a walk can reach it.  Here every lane encodes FIVE blocks in a row on one slab: lanes 0-3 a
+    64 KiB block, a 70 000-byte block (32-bit heads), a 64 KiB block, a short one and another 64 KiB one, of mixed
+    distributions; the other lanes five blocks of 300 - 9000 bytes, some with long repeats (the repeat optimisation
+    rewires chains).  Every block must be the oracle's bytes."""
+    rng = np.random.default_rng(17)
+    rows = 5
+    blocks = [None] * (64 * rows)
+    big = [65536, 70000, 65536, 4000, 65536]
+    for lane in range(64):
+        for r in range(rows):
+            if lane < 4:
+                sz = big[r] - (lane * 7 if r != 1 else 0)
+                dist = (2, 3, 2, 3)[(lane + r) % 4]
+            else:
+                sz = int(rng.integers(300, 9000))
+                dist = 2 if (lane + r) % 3 else 3
+            row = oracle.gen(dist, 100 + r, lane, (sz + 65535) // 65536).reshape(-1)[:sz].copy()
+            if lane >= 4 and (lane + r) % 5 == 0:
+                row[sz // 2:] = row[:sz - sz // 2]
+            if lane >= 4 and (lane + r) % 7 == 0:
+                row[: sz // 3] = 7                                    # a long run: every position hashes to one bucket
+            blocks[r * 64 + lane] = row
+    res, dst = emu.encode_hc_lane_static(blocks)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+
+
 def test_encode_lane_many_blocks_per_lane(oracle):
     """The lane encoder stamps its table entries with a per-lane block counter and zeroes the table only when the
     counter wraps (63 blocks) or after a block of the generic variant: a lane that encodes many blocks in a row,

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
-from lz4net_amd import batch
+from lz4net_amd import batch, _lib
 for dist in (2, 3):
     nmax = 1 << 16
     raw = batch.synth(dist, 3, 0, nmax)
@@ -12,7 +12,7 @@ for dist in (2, 3):
     for n in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
         row = []
         for name in ("wave", "lane"):
-            os.environ["LZ4HIP_DECODER"] = name
+            _lib.tuning_set("decoder", name)
             batch.decode(comp[:n], clen[:n], back[:n], batch.BLOCK)
             torch.cuda.synchronize()
             best = None

@@ -3,7 +3,7 @@ import os
 import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
-from lz4net_amd import batch
+from lz4net_amd import batch, _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 settings = sys.argv[2].split(",") if len(sys.argv) > 2 else ["4", "8", "16", "20"]
@@ -11,7 +11,7 @@ for dist in (2, 3):
     raw = batch.synth(dist, 7, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
     for wpc in settings:
-        os.environ["LZ4HIP_HC_WAVES_PER_CU"] = wpc
+        _lib.tuning_set("hc_waves_per_cu", int(wpc))
         batch.encode(raw[:4096], batch.BLOCK, comp[:4096], batch.BOUND, hc=True)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -2,14 +2,14 @@
 import os, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
-from lz4net_amd import batch
+from lz4net_amd import batch, _lib
 nmax = 1 << 16
 raw = batch.synth(2, 3, 0, nmax)
 comp = torch.empty((nmax, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
 for n in (4096, 8192, 16384, 32768, 65536):
     row = []
     for name in ("wave", "lane"):
-        os.environ["LZ4HIP_HC"] = name
+        _lib.tuning_set("hc", name)
         batch.encode(raw[:256], batch.BLOCK, comp[:256], batch.BOUND, hc=True)
         torch.cuda.synchronize()
         best = None
