@@ -120,6 +120,9 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 persistent lane-per-block encoder grids (0 = built-in default)
  *   "hc_groups"                  [LZ4HIP_HC_GROUPS]  wavefronts of the LZ4HC lane grid (0 = from the residency)
  *   "host_threads", "host_slices" [LZ4HIP_HOST_THREADS, LZ4HIP_HOST_SLICES]  host-pointer batches: gather/scatter threads, slices per batch
+ *   "decoder_gen", "decoder_ring" [LZ4HIP_DECODER_GEN, LZ4HIP_DECODER_RING]  lane decoder generation (0 default, 2, 3) and, for
+ *                                 generation 3, the bytes of output ring per lane (0 default; other sizes exist only in
+ *                                 libraries built with -DLZ4HIP_TUNING_BUILD)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

@@ -25,7 +25,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         if not os.path.exists(HIPCC):
             raise RuntimeError(f"{HIPCC} not found and {SO} is missing or stale: cannot build the gfx950 library")
-        cmd = [HIPCC, *FLAGS, os.path.join(CSRC, "lz4hip_api.hip"), "-o", SO]
+        extra = os.environ.get("LZ4HIP_BUILD_FLAGS", "").split()      # e.g. -DLZ4HIP_TUNING_BUILD (extra kernel instantiations for sweeps)
+        cmd = [HIPCC, *FLAGS, *extra, os.path.join(CSRC, "lz4hip_api.hip"), "-o", SO]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

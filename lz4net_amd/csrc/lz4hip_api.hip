@@ -7,6 +7,7 @@
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
+#include "lz4hip_decode_lane3.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
@@ -40,7 +41,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -48,6 +49,8 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "hc_groups", "LZ4HIP_HC_GROUPS", false },                     // persistent grid of the LZ4HC lane kernel (tests: few lanes, many blocks each)
     { "host_threads", "LZ4HIP_HOST_THREADS", false }, { "host_slices", "LZ4HIP_HOST_SLICES", false },
     { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
+    { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
+    { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -70,6 +73,7 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
+constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
 
 int fail(int code, const std::string& what)
 {
@@ -318,8 +322,44 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU; the
         // other ring / staging sizes that were measured are in profiles/r02/decoder_ab_*.txt).
         constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
-        if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
-        else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+        const int gen = knob(kKnobDecoderGen) ? knob(kKnobDecoderGen) : kLaneDecodeGeneration;
+        if (gen == 2) {
+            if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+            else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+        } else {
+            const int ring = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane3RingBytes;
+#define LZ4HIP_LAUNCH_LANE3(RING)                                                                                               \
+            do {                                                                                                                \
+                if (known) hipLaunchKernelGGL((decode_lane3_kernel<true, RING, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane3_kernel<false, RING, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+            } while (0)
+#define LZ4HIP_LAUNCH_LANE3_POL(RING, POL)                                                                                      \
+            do {                                                                                                                \
+                if (known) hipLaunchKernelGGL((decode_lane3_kernel<true, RING, 64, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane3_kernel<false, RING, 64, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+            } while (0)
+            switch (ring) {
+            case kLane3RingBytes: LZ4HIP_LAUNCH_LANE3(kLane3RingBytes); break;
+#ifdef LZ4HIP_TUNING_BUILD                                              /* residency vs near-window sweeps (tools/ab) */
+            case 1128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 1>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;   // 1000 * policy + ring (known size only)
+            case 2128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 2>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 3128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 3160: hipLaunchKernelGGL((decode_lane3_kernel<true, 160, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 3176: hipLaunchKernelGGL((decode_lane3_kernel<true, 176, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 3240: hipLaunchKernelGGL((decode_lane3_kernel<true, 240, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 160: LZ4HIP_LAUNCH_LANE3(160); break;
+            case 176: LZ4HIP_LAUNCH_LANE3(176); break;
+            case 192: LZ4HIP_LAUNCH_LANE3(192); break;
+            case 240: LZ4HIP_LAUNCH_LANE3(240); break;
+            case 256: LZ4HIP_LAUNCH_LANE3(256); break;
+            case 272: LZ4HIP_LAUNCH_LANE3(272); break;
+            case 368: LZ4HIP_LAUNCH_LANE3(368); break;
+#endif
+            default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no lane decoder with that ring size");
+            }
+#undef LZ4HIP_LAUNCH_LANE3
+#undef LZ4HIP_LAUNCH_LANE3_POL
+        }
         count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {

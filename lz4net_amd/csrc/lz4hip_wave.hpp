@@ -46,8 +46,8 @@ LZ4HIP_DEVICE uint32_t readlane(uint32_t v, int src_lane) { return (uint32_t)__b
 // Arbitrary cross-lane gather (ds_bpermute_b32): lane i receives v from lane idx_i.
 LZ4HIP_DEVICE uint32_t shuffle(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 
-LZ4HIP_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
-LZ4HIP_DEVICE bool any(bool p) { return __ballot(p) != 0ull; }
+LZ4HIP_DEVICE uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // (takes the lane mask the compare produced; __ballot() goes through an integer)
+LZ4HIP_DEVICE bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // number of set bits of a wave-uniform mask below this lane's bit (v_mbcnt_lo/hi)
 LZ4HIP_DEVICE int rank_below(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
@@ -100,6 +100,52 @@ LZ4HIP_DEVICE void load16(const void* p, uint32_t& a, uint32_t& b, uint32_t& c, 
 {
     const u32x4_unaligned v = *(const u32x4_unaligned*)p;
     a = v.x; b = v.y; c = v.z; d = v.w;
+}
+
+// ---- hand-counted vector memory (lz4hip_decode_lane3.hpp) ---------------------------------------------------------------
+// A loop that issues the SAME NUMBER of vector-memory instructions every iteration can wait with s_waitcnt vmcnt(N) for
+// the loads of the PREVIOUS iteration while this iteration's are still in flight (gfx9 returns loads and stores of a
+// wavefront in issue order and counts both in vmcnt).  The compiler only does that counting in straight-line code, so
+// these accesses are inline assembly: predicated by an exec mask INSIDE the asm (the instruction is always issued, with an
+// empty mask if need be -- it still counts), invisible to the compiler's own s_waitcnt insertion, and ordered against
+// their users by vm_wait<N>(), which takes the destination registers as in/out operands.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// POLICY: 0 = default cache policy, 1 = nt (non-temporal: the line is the first to go from the L2)
+template <int POLICY = 0>
+LZ4HIP_DEVICE void vm_load16_pred(bool pred, uint64_t addr, u32x4& v)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+    uint64_t saved;
+    if (POLICY == 1)
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off nt\n\ts_mov_b64 exec, %[sv]"
+                     : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory");
+    else
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
+                     : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory");
+}
+LZ4HIP_DEVICE void vm_store16_pred(bool pred, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+    uint64_t saved;
+    const u32x4 v = { a, b, c, d };
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_store_dwordx4 %[a], %[d], off\n\ts_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved) : [a] "v"(addr), [d] "v"(v), [m] "s"(m) : "memory");
+}
+// At most N of this wavefront's vector-memory instructions are still in flight afterwards; `a` and `b` (destinations of
+// vm_load16_pred) may not be read before.
+template <int N>
+LZ4HIP_DEVICE void vm_wait(u32x4& a, u32x4& b)
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N) : "memory");
+}
+
+// DS_MSKOR_B32: MEM = (MEM & ~mask) | data -- a byte-granular merge into an aligned LDS dword without reading it back.
+// (An LDS instruction the compiler does not know about only makes its own lgkmcnt waits stricter: LDS operations of a
+// wavefront complete in issue order.)
+LZ4HIP_DEVICE void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data)
+{
+    asm volatile("ds_mskor_b32 %[a], %[m], %[d]" : : [a] "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p), [m] "v"(mask), [d] "v"(data) : "memory");
 }
 
 LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }

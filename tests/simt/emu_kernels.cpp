@@ -9,6 +9,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
+#include "lz4hip_decode_lane3.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_synth.hpp"
@@ -58,6 +59,26 @@ void emu_decode_lane(int known, const uint8_t* src, int64_t src_stride, const in
     else if (stage == 64) EMU_LANE(256, 64);
     else EMU_LANE(256, 128);
 #undef EMU_LANE
+}
+
+// third-generation lane decoder (lz4hip_decode_lane3.hpp); `ring` = bytes of output ring per lane
+void emu_decode_lane3(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                      int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int ring, int stage)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+#define EMU_LANE3(R, SB)                                                                                                        \
+    do {                                                                                                                        \
+        if (known) simt::launch(grid, block, lane3_lds_bytes(R, SB), [=] { decode_lane3_kernel<true, R, SB>(b, filter); });        \
+        else       simt::launch(grid, block, lane3_lds_bytes(R, SB), [=] { decode_lane3_kernel<false, R, SB>(b, filter); });       \
+    } while (0)
+    if (ring == 128) EMU_LANE3(128, 64);
+    else if (ring == 176) EMU_LANE3(176, 64);
+    else if (ring == 240) EMU_LANE3(240, 64);
+    else if (ring == 256 && stage == 128) EMU_LANE3(256, 128);
+    else if (ring == 256) EMU_LANE3(256, 64);
+    else simt::die("emu_decode_lane3: ring size not instantiated", ring, stage);
+#undef EMU_LANE3
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

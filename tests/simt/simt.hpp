@@ -35,7 +35,11 @@ namespace simt {
 
 enum WaitKind { WAIT_NONE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2 };
 
+// a vector-memory load issued through wv::vm_load16_pred and not yet waited for (wv::vm_wait<N>): address + destination
+struct PendingVm { uint64_t addr; uint32_t* dst; bool is_load; };
+
 struct Lane {
+    std::vector<PendingVm> vmq;   // in issue order
     ucontext_t ctx;
     std::vector<unsigned char> stack;
     int tid = 0;            // thread index in block
@@ -106,6 +110,7 @@ inline void run_block(size_t lds_bytes)
         Lane& l = r.lanes[(size_t)t];
         if (l.stack.empty()) l.stack.resize(256 * 1024);
         l.tid = t; l.done = false; l.wait_kind = WAIT_NONE; l.seq = 0; l.slot_tag[0] = l.slot_tag[1] = ~0u;
+        l.vmq.clear();
         getcontext(&l.ctx);
         l.ctx.uc_stack.ss_sp = l.stack.data();
         l.ctx.uc_stack.ss_size = l.stack.size();

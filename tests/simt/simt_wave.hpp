@@ -126,6 +126,34 @@ inline void load16(const void* p, uint32_t& a, uint32_t& b, uint32_t& c, uint32_
     a = v[0]; b = v[1]; c = v[2]; d = v[3];
 }
 
+// ---- hand-counted vector memory (lz4hip_decode_lane3.hpp) ----
+// The emulation is ASYNCHRONOUS on purpose: a load only writes its destination when a vm_wait<N> retires it (and reads
+// memory at that moment, the latest the hardware could), so a kernel that reads the destination registers before the
+// wait that covers them, or miscounts N, sees stale data here too.  Every call counts as one instruction for every lane
+// of the wavefront (the hardware issues it with an empty mask).
+struct u32x4 { uint32_t x, y, z, w; };
+template <int POLICY = 0>
+inline void vm_load16_pred(bool pred, uint64_t addr, u32x4& v)
+{
+    simt::rt().cur->vmq.push_back(simt::PendingVm{ pred ? addr : 0, (uint32_t*)&v, true });
+}
+inline void vm_store16_pred(bool pred, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    if (pred) { const uint32_t v[4] = { a, b, c, d }; __builtin_memcpy((void*)addr, v, 16); }
+    simt::rt().cur->vmq.push_back(simt::PendingVm{ 0, nullptr, false });
+}
+template <int N>
+inline void vm_wait(u32x4&, u32x4&)
+{
+    auto& q = simt::rt().cur->vmq;
+    while ((int)q.size() > N) {
+        const simt::PendingVm op = q.front();
+        q.erase(q.begin());
+        if (op.is_load && op.addr) __builtin_memcpy(op.dst, (const void*)op.addr, 16);
+    }
+}
+inline void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data) { *p = (*p & ~mask) | data; }
+
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 

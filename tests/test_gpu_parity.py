@@ -363,10 +363,14 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
     sizes = [t for _, t in cs]
     pad = [np.concatenate([c, np.zeros(t + 1024, np.uint8)]) for c, t in zip(comps, sizes)]
     res, dst = gpu.decode(pad, sizes, known=True)
+    # (a match with offset 0 keeps what the destination held: through the host-pointer entry points that is the device staging
+    #  image, not the caller's buffer, so the BYTES of such streams are not comparable here -- return codes and canaries are;
+    #  the emulator twin compares the bytes as well)
+    holes = [stream_fuzz.has_zero_offset(c, t + 8) for c, t in zip(comps, sizes)]
     for i, (c, t) in enumerate(zip(comps, sizes)):
         w, out = oracle.uncompress_raw(c, t)
         assert res[i] == w, ("known", i, res[i], w)
-        if w >= 0:
+        if w >= 0 and not holes[i]:
             assert np.array_equal(dst[i, :t], out[:t]), ("known", i)
         assert (dst[i, t:] == 0xA5).all(), ("known canary", i)
     caps = [t + (i % 3) * 7 - (5 if i % 11 == 0 else 0) for i, t in enumerate(sizes)]
@@ -375,7 +379,7 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
     for i, (c, cap) in enumerate(zip(comps, caps)):
         w, out = oracle.uncompress_unknown_raw(c, len(c), cap)
         assert res[i] == w, ("unknown", i, res[i], w)
-        if w >= 0:
+        if w >= 0 and not holes[i]:
             assert np.array_equal(dst[i, :w], out[:w]), ("unknown", i)
         assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)
 

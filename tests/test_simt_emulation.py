@@ -12,10 +12,16 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
+    if isinstance(m, str) and m.startswith("l3r"):                   # "l3r240": third-generation lane decoder, ring 240 (staging 64)
+        ring, _, stage = m[3:].partition("s")
+        return dict(lane=int(ring), stage=int(stage or 64), gen=3)
     if isinstance(m, str):
         ring, _, stage = m[4:].partition("s")                        # "lane128s64": ring 128, staging 64
         return dict(lane=int(ring), stage=int(stage or 64))
     return {}
+
+
+LANE3 = ["l3r128", "l3r176", "l3r240", "l3r256s128"]
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
@@ -32,7 +38,7 @@ def _blocks(oracle, sizes=SIZES, seeds=(5,)):
     return out
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"] + LANE3, ids=["wave-per-block", "lane128s64", "lane256s128"] + LANE3)
 def test_decode_known_size(oracle, lane):
     blocks = _blocks(oracle)
     for hc in (False, True):
@@ -53,7 +59,7 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"] + LANE3, ids=["wave-per-block", "lane128s64", "lane256s128"] + LANE3)
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -65,7 +71,7 @@ def test_decode_unknown_size(oracle, lane):
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"] + LANE3, ids=["wave-per-block", "lane128s64", "lane256s128"] + LANE3)
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
@@ -263,7 +269,7 @@ def test_encode_lane_many_blocks_per_lane(oracle):
 
 
 
-@pytest.mark.parametrize("mapping", ["lane128s64", "lane128s128", "lane256s64", "lane256s128"])
+@pytest.mark.parametrize("mapping", ["lane128s64", "lane128s128", "lane256s64", "lane256s128"] + LANE3)
 def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
     """64 identical blocks keep the 64 lanes of the lane-mapped decoder in lockstep, so every lane wants to flush in
     the same iteration (four rounds of the cooperative flush) -- on blocks built to contain matches of every length
@@ -290,7 +296,8 @@ def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
-def test_lane_decoder_starved_flush(oracle):
+@pytest.mark.parametrize("gen", [2, 3])
+def test_lane_decoder_starved_flush(oracle, gen):
     """The lane decoder with its cooperative flush cut down to 4 lines per round: with 64 busy lanes most of them miss
     flush rounds several times in a row, run their output rings full and sit out iterations -- also while the first or the
     next 16 bytes of a far match have already been fetched for them (those must be fetched again, not skipped).  Blocks:
@@ -312,16 +319,16 @@ def test_lane_decoder_starved_flush(oracle):
             comps = [oracle.compress(a) for a in blocks]
             for known in (True, False):
                 res, dst = emu.decode([np.concatenate([c, np.zeros(64, np.uint8)]) for c in comps], [a.size for a in blocks], known=known,
-                                      src_lens=None if known else [len(c) for c in comps], lane=128, stage=64)
+                                      src_lens=None if known else [len(c) for c in comps], lane=128, stage=64, gen=gen)
                 for i, (a, c) in enumerate(zip(blocks, comps)):
                     assert res[i] == (len(c) if known else a.size), (known, i, res[i])
                     assert np.array_equal(dst[i, :a.size], a), (known, i)
         # the odd-but-legal and malformed streams and the error-code matrix, in the same starved state
-        test_decode_arbitrary_streams(oracle, "lane128s64")
-        test_decode_error_codes_match_oracle(oracle, "lane128s64")
+        test_decode_arbitrary_streams(oracle, "lane128s64" if gen == 2 else "l3r128")
+        test_decode_error_codes_match_oracle(oracle, "lane128s64" if gen == 2 else "l3r128")
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"], ids=["wave-per-block", "lane128s64", "lane256s128"])
+@pytest.mark.parametrize("lane", [False, "lane128s64", "lane256s128"] + LANE3, ids=["wave-per-block", "lane128s64", "lane256s128"] + LANE3)
 def test_decode_arbitrary_streams(oracle, lane):
     """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
     them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching
