@@ -12,6 +12,7 @@
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
+#include "lz4hip_hc_conv.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
@@ -41,7 +42,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -51,6 +52,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
     { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
     { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
+    { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default, 1 lz4hip_hc_lane.hpp, 2 lz4hip_hc_conv.hpp (convergent state machine)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -74,6 +76,7 @@ constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
+constexpr int kHcLaneGeneration = 2;
 
 int fail(int code, const std::string& what)
 {
@@ -275,8 +278,19 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             }
             if (ws) {
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                                   (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
+                const int hc_gen = knob(kKnobHcGen) ? knob(kKnobHcGen) : kHcLaneGeneration;
+                if (hc_gen == 2 && small)
+                    hipLaunchKernelGGL(encode_hc_conv_kernel<uint16_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                       (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
+                else if (hc_gen == 2)
+                    hipLaunchKernelGGL(encode_hc_conv_kernel<uint32_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                       (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
+#ifdef LZ4HIP_TUNING_BUILD                                              /* round-2 kernel, for A/B runs (tools/hc_gen_ab.py) */
+                else if (hc_gen == 1)
+                    hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                       (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
+#endif
+                else return fail(LZ4HIP_E_ARGUMENT, "hc_gen: this library has no LZ4HC lane kernel of that generation");
                 HIP_TRY(hipGetLastError());
                 count_dispatch(LZ4HIP_K_HC_LANE);
                 return lease_end(lease, stream);
@@ -323,10 +337,14 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         // other ring / staging sizes that were measured are in profiles/r02/decoder_ab_*.txt).
         constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
         const int gen = knob(kKnobDecoderGen) ? knob(kKnobDecoderGen) : kLaneDecodeGeneration;
+#ifdef LZ4HIP_TUNING_BUILD                                              /* round-2 kernel, for A/B runs (tools/ab_decoder_knobs.py) */
         if (gen == 2) {
             if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
             else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
-        } else {
+        } else
+#endif
+        if (gen != 3) return fail(LZ4HIP_E_ARGUMENT, "decoder_gen: this library has no lane decoder of that generation");
+        else {
             const int ring = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane3RingBytes;
 #define LZ4HIP_LAUNCH_LANE3(RING)                                                                                               \
             do {                                                                                                                \

@@ -67,14 +67,14 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     elif lane:
         lib().emu_decode_lane(*args, 0, lane, stage)
     elif auto:        # the library's default: the batch is partitioned between the two mappings
-        lib().emu_decode_lane(*args, 2, 128, 64)
+        lib().emu_decode_lane3(*args, 2, 128, 64)
         lib().emu_decode(*args, waves_per_group, 1)
     else:
         lib().emu_decode(*args, waves_per_group, 0)
     return res, dst
 
 
-def encode(blocks, caps=None, hc=False, groups=2, lane=False):
+def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False):
     src, sl = pack(blocks)
     if caps is None:
         caps = [len(b) + len(b) // 255 + 16 for b in blocks]
@@ -83,7 +83,9 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False):
     dst = np.full((len(blocks), ds), 0xA5, np.uint8)
     res = np.zeros(len(blocks), np.int32)
     args = (_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
-    if hc and lane:
+    if hc and conv:
+        lib().emu_encode_hc_conv(*args, 1, int(max(len(b) for b in blocks) > 65536))
+    elif hc and lane:
         lib().emu_encode_hc_lane(*args, 1, int(max(len(b) for b in blocks) > 65536))
     elif hc:
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))

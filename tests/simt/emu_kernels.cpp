@@ -16,6 +16,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #ifdef LZ4HIP_HAVE_HC
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
+#include "lz4hip_hc_conv.hpp"
 #endif
 
 using namespace lz4hip;
@@ -170,6 +171,23 @@ void emu_encode_hc_lane_static(const uint8_t* src, int64_t src_stride, const int
     ws.assign((size_t)64 * kHcLaneSlab32, 0x5A);                    // poisoned once; afterwards whatever the previous block left
     uint8_t* slabs = ws.data();
     simt::launch(dim3(1), dim3(64), 0, [=] { hc_lane_static_kernel(b, slabs, (unsigned long long)kHcLaneSlab32); });
+}
+#endif
+
+#ifdef LZ4HIP_HAVE_HC
+// convergent lane-per-block LZ4HC (lz4hip_hc_conv.hpp): same launch shape as emu_encode_hc_lane
+void emu_encode_hc_conv(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                        int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups, int heads32)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    const size_t slab = heads32 ? kHcLaneSlab32 : kHcLaneSlab16;
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)groups * 64 * slab, 0x5A);      // poisoned
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* slabs = ws.data() + 256;
+    if (heads32) simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_conv_kernel<uint32_t>(b, counter, slabs, (unsigned long long)slab); });
+    else         simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_conv_kernel<uint16_t>(b, counter, slabs, (unsigned long long)slab); });
 }
 #endif
 

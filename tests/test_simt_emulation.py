@@ -179,30 +179,31 @@ def test_checksum_and_compare(oracle):
     assert emu.compare(a, b, [5000] * 5) == 3
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "conv"], ids=["wave-per-block", "lane-per-block", "lane-per-block-convergent"])
 def test_encode_hc_bit_exact(oracle, lane):
     # LZ4HC: several blocks per persistent workgroup (stale-state check), 16- and 32-bit heads
     sizes = (0, 1, 12, 13, 14, 64, 300, 4096) if not lane else (0, 1, 12, 13, 14, 64, 300, 4096, 20000, 65536)
     blocks = _blocks(oracle, sizes=sizes)
-    res, dst = emu.encode(blocks, hc=True, groups=2, lane=lane)
+    conv = lane == "conv"
+    res, dst = emu.encode(blocks, hc=True, groups=2, lane=bool(lane), conv=conv)
     for i, a in enumerate(blocks):
         want = oracle.compress(a, hc=True)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
         assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
     big = [oracle.gen(2, 3, 0, 1, 70000)[0]] + ([oracle.gen(3, 3, 0, 1, 65536)[0]] if not lane else [])
-    res, dst = emu.encode(big, hc=True, groups=1, lane=lane)
+    res, dst = emu.encode(big, hc=True, groups=1, lane=bool(lane), conv=conv)
     for i, a in enumerate(big):
         want = oracle.compress(a, hc=True)
         assert res[i] == len(want) and np.array_equal(dst[i, :res[i]], want), (i, a.size)
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "conv"], ids=["wave-per-block", "lane-per-block", "lane-per-block-convergent"])
 def test_encode_hc_limited_output(oracle, lane):
     blocks = _blocks(oracle, sizes=(13, 300, 4096) if lane else (13, 300))
     lens = [len(oracle.compress(a, hc=True)) for a in blocks]
     for delta in (0, -1, -7):
         caps = [max(l + delta, 0) for l in lens]
-        res, dst = emu.encode(blocks, caps=caps, hc=True, lane=lane)
+        res, dst = emu.encode(blocks, caps=caps, hc=True, lane=bool(lane), conv=lane == "conv")
         for i, a in enumerate(blocks):
             want = oracle.compress_raw(a, caps[i], hc=True)[0]
             assert res[i] == want, (i, delta, res[i], want)
@@ -235,6 +236,27 @@ def test_encode_hc_lane_slab_reuse(oracle):
                 row[: sz // 3] = 7                                    # a long run: every position hashes to one bucket
             blocks[r * 64 + lane] = row
     res, dst = emu.encode_hc_lane_static(blocks)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+
+
+def test_encode_hc_conv_slab_reuse(oracle):
+    """The convergent LZ4HC kernel with ONE wavefront in its persistent grid: 64 lanes, 3 blocks each (handed out through the
+    counter), 64 KiB / 70 000-byte (32-bit heads) / short blocks mixed, fuzzer-style and record-like, some with long repeats
+    (the repeat optimisation) and long runs -- slabs are never re-initialised beyond the heads and chain[0]."""
+    rng = np.random.default_rng(19)
+    blocks = []
+    for i in range(192):
+        sz = 65536 if i == 3 else 70000 if i == 70 else 65000 if i == 131 else int(rng.integers(300, 5000))   # (lane 3: 64 KiB, then one of the short ones; lane 6: 70 000 bytes second; ...)
+        row = oracle.gen(2 if i % 3 else 3, 200 + i % 7, i, (sz + 65535) // 65536).reshape(-1)[:sz].copy()
+        if i % 6 == 0:
+            row[sz // 2:] = row[:sz - sz // 2]
+        if i % 11 == 0:
+            row[: sz // 4] = 9
+        blocks.append(row)
+    res, dst = emu.encode(blocks, hc=True, conv=True, groups=1)
     for i, a in enumerate(blocks):
         want = oracle.compress(a, hc=True)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
