@@ -519,7 +519,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if wave_mapped
-                       else "lz4hip::decode_lane_kernel<true,...> (one lane per block, LDS input staging + output ring)"),
+                       else "lz4hip::decode_lane3_kernel<true,128,64,0> (one lane per block, LDS input staging + output ring, hand-counted vmcnt)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),
@@ -527,7 +527,7 @@ def main():
         # BASELINE configs[2] / [3]: one launch over the batch, HIP events on the launch stream, same algorithmic bytes
         "roofline_encode": side_roofline(enc_roof, "encode_fast", "lz4hip::encode_fast_kernel (one wavefront per block, 64-probe search, hands dense blocks over) + "
                                          "lz4hip::encode_fast_lane_kernel (LZ4_compress64kCtx, one lane per block, the blocks handed over)", enc_check),
-        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::encode_hc_lane_kernel (LZ4_compressHCCtx, one lane per block)", hc_check),
+        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::encode_hc_conv_kernel<unsigned short> (LZ4_compressHCCtx, one lane per block, convergent state machine)", hc_check),
         "cpu_baseline": cpu,
         "verified": all_ok,
         "csrc_sha": csrc_sha(),

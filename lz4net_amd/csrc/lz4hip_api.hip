@@ -335,10 +335,10 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
         // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU; the
         // other ring / staging sizes that were measured are in profiles/r02/decoder_ab_*.txt).
-        constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
         const int gen = knob(kKnobDecoderGen) ? knob(kKnobDecoderGen) : kLaneDecodeGeneration;
 #ifdef LZ4HIP_TUNING_BUILD                                              /* round-2 kernel, for A/B runs (tools/ab_decoder_knobs.py) */
         if (gen == 2) {
+            constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
             if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
             else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
         } else

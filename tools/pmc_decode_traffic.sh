@@ -15,11 +15,12 @@ import csv, glob, json, sys, collections
 out, dist, blocks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 vals = collections.defaultdict(list)
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if 'decode_lane_kernel' in r['Kernel_Name'] or 'decode_kernel' in r['Kernel_Name']]
-    big = max(int(r['Grid_Size']) for r in rows if 'decode_lane_kernel' in r['Kernel_Name'])
+    lane = lambda r: 'decode_lane3_kernel' in r['Kernel_Name'] or 'decode_lane_kernel' in r['Kernel_Name']
+    rows = [r for r in csv.DictReader(open(f)) if lane(r) or 'decode_kernel' in r['Kernel_Name']]
+    big = max(int(r['Grid_Size']) for r in rows if lane(r))
     per = collections.defaultdict(float); n = collections.Counter()
     for r in rows:
-        if 'decode_lane_kernel' in r['Kernel_Name'] and int(r['Grid_Size']) == big:
+        if lane(r) and int(r['Grid_Size']) == big:
             per[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
     for c, v in per.items():
         vals[c] = v / n[c]

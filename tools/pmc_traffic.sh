@@ -2,7 +2,7 @@
 # HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes as the MI355X guide prescribes) of the
 # three timed kernels of the default bench workload: decode (2^20 blocks), fast encode (2^20), LZ4HC (2^18).
 # Writes gpurun_out/pmc_traffic/pmc_traffic.json keyed on the hash of lz4net_amd/csrc (bench.py only quotes it when
-# the hash matches); copy it to profiles/r02/ to commit it.
+# the hash matches); copy it to profiles/r03/ to commit it.
 # Usage: bash tools/pmc_traffic.sh [dist] [blocks] [hc_blocks]
 dist=${1:-2}; blocks=${2:-1048576}; hcb=${3:-262144}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
@@ -10,7 +10,7 @@ rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $pmc -d $out/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu --hc-only --blocks $blocks --hc-blocks $hcb --dist $dist > $out/bench_$i.json 2>> $out/err.txt
+  timeout 360 rocprofv3 --pmc $pmc -d $out/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu --hc-only --blocks $blocks --hc-blocks $hcb --dist $dist > $out/bench_$i.json 2>> $out/err.txt
 done
 cd $GRAFT_REPO_ROOT
 python - $out $dist $blocks $hcb <<'PY'
@@ -19,7 +19,7 @@ sys.path.insert(0, '.')
 import bench
 out, dist, blocks, hcb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 # per kernel family: the dispatches with the largest grid are the full-size launches; average their counters
-fam = {"decode": ("decode_lane_kernel", "decode_kernel"), "encode_fast": ("encode_fast_lane_kernel", "encode_fast_kernel"), "encode_hc": ("encode_hc_lane_kernel",)}
+fam = {"decode": ("decode_lane3_kernel", "decode_lane_kernel", "decode_kernel"), "encode_fast": ("encode_fast_lane_kernel", "encode_fast_kernel"), "encode_hc": ("encode_hc_conv_kernel", "encode_hc_lane_kernel")}
 vals = {k: collections.defaultdict(list) for k in fam}
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     rows = list(csv.DictReader(open(f)))

@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- \
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-extras --no-cpu > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
 cd $GRAFT_REPO_ROOT
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
