@@ -31,6 +31,56 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+// ---- fiber switch ---------------------------------------------------------------------------------------------------------
+// glibc's swapcontext() saves and restores the signal mask: two system calls per switch, and the emulator switches fibers
+// millions of times per test.  On x86-64 a switch only has to exchange the callee-saved registers and the stack pointer
+// (System V ABI); everywhere else ucontext is used as it is.
+#if defined(__x86_64__)
+extern "C" void simt_switch_stack(void** save_sp, void* const* load_sp);
+asm(R"(
+    .text
+    .globl simt_switch_stack
+    .type simt_switch_stack,@function
+simt_switch_stack:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size simt_switch_stack, .-simt_switch_stack
+)");
+struct FiberCtx { void* sp = nullptr; };
+inline void fiber_switch(FiberCtx* from, FiberCtx* to) { simt_switch_stack(&from->sp, &to->sp); }
+inline void fiber_make(FiberCtx* c, unsigned char* stack, size_t bytes, void (*entry)())
+{
+    uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // the entry function's "return address": it never returns
+    *--sp = (void*)entry;            // popped by the `ret` of the first switch into this fiber
+    for (int k = 0; k < 6; k++) *--sp = nullptr;   // rbp, rbx, r12 .. r15
+    c->sp = (void*)sp;
+}
+#else
+struct FiberCtx { ucontext_t uc; };
+inline void fiber_switch(FiberCtx* from, FiberCtx* to) { swapcontext(&from->uc, &to->uc); }
+inline void fiber_make(FiberCtx* c, unsigned char* stack, size_t bytes, void (*entry)())
+{
+    getcontext(&c->uc);
+    c->uc.uc_stack.ss_sp = stack; c->uc.uc_stack.ss_size = bytes; c->uc.uc_link = nullptr;
+    makecontext(&c->uc, entry, 0);
+}
+#endif
+
 namespace simt {
 
 enum WaitKind { WAIT_NONE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2 };
@@ -40,7 +90,7 @@ struct PendingVm { uint64_t addr; uint32_t* dst; bool is_load; };
 
 struct Lane {
     std::vector<PendingVm> vmq;   // in issue order
-    ucontext_t ctx;
+    FiberCtx ctx;
     std::vector<unsigned char> stack;
     int tid = 0;            // thread index in block
     bool done = false;
@@ -55,7 +105,7 @@ struct Runtime {
     dim3 grid, block, block_idx;
     std::vector<Lane> lanes;
     Lane* cur = nullptr;
-    ucontext_t sched;
+    FiberCtx sched;
     std::vector<unsigned char> lds;
     std::function<void()> body;
     uint64_t steps = 0;
@@ -79,7 +129,7 @@ inline void yield(int kind, int site)
     Lane* me = rt().cur;
     me->wait_kind = kind;
     me->wait_site = site;
-    swapcontext(&me->ctx, &rt().sched);
+    fiber_switch(&me->ctx, &rt().sched);
 }
 
 inline void trampoline()
@@ -88,7 +138,7 @@ inline void trampoline()
     r.body();
     r.cur->done = true;
     r.cur->wait_kind = WAIT_NONE;
-    swapcontext(&r.cur->ctx, &r.sched);
+    fiber_switch(&r.cur->ctx, &r.sched);
     die("resumed a finished lane");
 }
 
@@ -111,11 +161,7 @@ inline void run_block(size_t lds_bytes)
         if (l.stack.empty()) l.stack.resize(256 * 1024);
         l.tid = t; l.done = false; l.wait_kind = WAIT_NONE; l.seq = 0; l.slot_tag[0] = l.slot_tag[1] = ~0u;
         l.vmq.clear();
-        getcontext(&l.ctx);
-        l.ctx.uc_stack.ss_sp = l.stack.data();
-        l.ctx.uc_stack.ss_size = l.stack.size();
-        l.ctx.uc_link = nullptr;
-        makecontext(&l.ctx, (void (*)())trampoline, 0);
+        fiber_make(&l.ctx, l.stack.data(), l.stack.size(), (void (*)())trampoline);
     }
     const int nwaves = (nthreads + 63) / 64;
     std::vector<char> at_barrier((size_t)nwaves, 0);
@@ -133,7 +179,7 @@ inline void run_block(size_t lds_bytes)
                 Lane& l = r.lanes[(size_t)t];
                 if (l.done) continue;
                 r.cur = &l;
-                swapcontext(&r.sched, &l.ctx);
+                fiber_switch(&r.sched, &l.ctx);
                 r.steps++;
             }
             // every lane that is still alive must be waiting at the same rendezvous

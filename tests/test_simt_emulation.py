@@ -60,7 +60,7 @@ def test_decode_partitioned_between_mappings(oracle):
         assert res[i] == len(c) and np.array_equal(dst[i, :a.size], a), i
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64"] + LANE3, ids=["wave-per-block", "lane128s64"] + LANE3)
+@pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)
 def test_decode_unknown_size(oracle, lane):
     blocks = _blocks(oracle, sizes=(0, 1, 13, 300, 4096, 65536))
     comps = [oracle.compress(a) for a in blocks]
@@ -72,7 +72,7 @@ def test_decode_unknown_size(oracle, lane):
             assert (dst[i, a.size + extra:] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64"] + LANE3, ids=["wave-per-block", "lane128s64"] + LANE3)
+@pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)
 def test_decode_error_codes_match_oracle(oracle, lane):
     # wrong sizes and corrupted streams: same (negative) return codes as the reference decoders
     rng = np.random.default_rng(11)
@@ -243,13 +243,14 @@ def test_encode_hc_lane_slab_reuse(oracle):
 
 
 def test_encode_hc_conv_slab_reuse(oracle):
-    """The convergent LZ4HC kernel with ONE wavefront in its persistent grid: 64 lanes, 3 blocks each (handed out through the
+    """The convergent LZ4HC kernel with ONE wavefront in its persistent grid: 64 lanes, 5 blocks each (handed out through the
     counter), 64 KiB / 70 000-byte (32-bit heads) / short blocks mixed, fuzzer-style and record-like, some with long repeats
     (the repeat optimisation) and long runs -- slabs are never re-initialised beyond the heads and chain[0]."""
     rng = np.random.default_rng(19)
     blocks = []
-    for i in range(192):
-        sz = 65536 if i == 3 else 70000 if i == 70 else 65000 if i == 131 else int(rng.integers(300, 5000))   # (lane 3: 64 KiB, then one of the short ones; lane 6: 70 000 bytes second; ...)
+    for i in range(320):
+        k = int(rng.integers(0, 40))
+        sz = 65536 if k == 0 else 70000 if k == 1 else 65536 - int(rng.integers(1, 2000)) if k == 2 else int(rng.integers(300, 9000))
         row = oracle.gen(2 if i % 3 else 3, 200 + i % 7, i, (sz + 65535) // 65536).reshape(-1)[:sz].copy()
         if i % 6 == 0:
             row[sz // 2:] = row[:sz - sz // 2]
@@ -292,7 +293,7 @@ def test_encode_lane_many_blocks_per_lane(oracle):
 
 
 
-@pytest.mark.parametrize("mapping", ["lane128s64", "lane256s128"] + LANE3)
+@pytest.mark.parametrize("mapping", ["lane128s64"] + LANE3)
 def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
     """64 identical blocks keep the 64 lanes of the lane-mapped decoder in lockstep, so every lane wants to flush in
     the same iteration (four rounds of the cooperative flush) -- on blocks built to contain matches of every length
@@ -319,7 +320,7 @@ def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
-@pytest.mark.parametrize("gen", [2, 3])
+@pytest.mark.parametrize("gen", [3])
 def test_lane_decoder_starved_flush(oracle, gen):
     """The lane decoder with its cooperative flush cut down to 4 lines per round: with 64 busy lanes most of them miss
     flush rounds several times in a row, run their output rings full and sit out iterations -- also while the first or the
@@ -351,7 +352,7 @@ def test_lane_decoder_starved_flush(oracle, gen):
         test_decode_error_codes_match_oracle(oracle, "lane128s64" if gen == 2 else "l3r128")
 
 
-@pytest.mark.parametrize("lane", [False, "lane128s64"] + LANE3, ids=["wave-per-block", "lane128s64"] + LANE3)
+@pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)
 def test_decode_arbitrary_streams(oracle, lane):
     """Streams that no encoder of ours produced (tests/stream_fuzz.py): whatever the oracle's decoders return for
     them -- bytes and return code, well formed or not -- the kernels return too, for both decoders, without touching
