@@ -359,12 +359,11 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             switch (ring) {
             case kLane3RingBytes: LZ4HIP_LAUNCH_LANE3(kLane3RingBytes); break;
 #ifdef LZ4HIP_TUNING_BUILD                                              /* residency vs near-window sweeps (tools/ab) */
-            case 1128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 1>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;   // 1000 * policy + ring (known size only)
-            case 2128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 2>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
-            case 3128: hipLaunchKernelGGL((decode_lane3_kernel<true, 128, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
-            case 3160: hipLaunchKernelGGL((decode_lane3_kernel<true, 160, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
-            case 3176: hipLaunchKernelGGL((decode_lane3_kernel<true, 176, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
-            case 3240: hipLaunchKernelGGL((decode_lane3_kernel<true, 240, 64, 3>), dim3(grid), dim3(64), 0, stream, d, lane_filter); break;
+            case 1128: LZ4HIP_LAUNCH_LANE3_POL(128, 1); break;    // 1000 * policy + ring: far fetches nt / sc1 / sc0 sc1, input pieces nt
+            case 2128: LZ4HIP_LAUNCH_LANE3_POL(128, 2); break;
+            case 3128: LZ4HIP_LAUNCH_LANE3_POL(128, 3); break;
+            case 4128: LZ4HIP_LAUNCH_LANE3_POL(128, 4); break;
+            case 7128: LZ4HIP_LAUNCH_LANE3_POL(128, 7); break;
             case 160: LZ4HIP_LAUNCH_LANE3(160); break;
             case 176: LZ4HIP_LAUNCH_LANE3(176); break;
             case 192: LZ4HIP_LAUNCH_LANE3(192); break;

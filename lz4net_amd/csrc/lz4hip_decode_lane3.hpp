@@ -49,7 +49,7 @@ enum L3Kind { kK3None = 0, kK3Near = 1, kK3Far = 2, kK3Lit = 3, kK3Zero = 4 };
 enum L3Flag { kF3Final = 1, kF3Err = 2, kF3Header = 4 };   // pending sequence: final literal run / corrupt stream / no match yet (its header follows the literals)
 
 // All 64 lanes of the wavefront call this together and stay in the loop until the last one is done.
-// POL: cache policy of the loads, bit 0 = far-match fetches non-temporal, bit 1 = input pieces non-temporal
+// POL: cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
 template <bool KNOWN, int R, int SB, int POL = 0>
 LZ4HIP_DEVICE int lane3_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
                                      uint8_t* dst, int oend)
@@ -310,7 +310,7 @@ LZ4HIP_DEVICE int lane3_decode_block(unsigned char* lds, int lane, bool active, 
             const int f_pos = f_cont ? op + n - off : op_end + p_ll - p_off;
             const bool f_want = f_cont | f_first;
             const bool f_do = f_want & (f_pos + 16 <= fl);
-            wv::vm_load16_pred<POL & 1>(f_do, (uint64_t)dst + (uint64_t)(uint32_t)f_pos, ldF);
+            wv::vm_load16_pred<POL & 3>(f_do, (uint64_t)dst + (uint64_t)(uint32_t)f_pos, ldF);
             flush_blocked = (f_want & !f_do) ? 1 : 0;
             gready = f_do ? 1 : 0;                                   // (only read while kind == kK3Far)
         }
@@ -347,7 +347,7 @@ LZ4HIP_DEVICE int lane3_decode_block(unsigned char* lds, int lane, bool active, 
             }
             ld_hvalid = hv ? 1 : 0;
             ld_inflight = go;
-            wv::vm_load16_pred<(POL >> 1) & 1>(hv, g, ldH);
+            wv::vm_load16_pred<(POL >> 2) & 3>(hv, g, ldH);
         }
         }
 

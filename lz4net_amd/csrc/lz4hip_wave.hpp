@@ -110,18 +110,21 @@ LZ4HIP_DEVICE void load16(const void* p, uint32_t& a, uint32_t& b, uint32_t& c, 
 // empty mask if need be -- it still counts), invisible to the compiler's own s_waitcnt insertion, and ordered against
 // their users by vm_wait<N>(), which takes the destination registers as in/out operands.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// POLICY: 0 = default cache policy, 1 = nt (non-temporal: the line is the first to go from the L2)
+// POLICY: 0 = default cache policy, 1 = nt (non-temporal: the line is the first to go from the L2), 2 = sc1, 3 = sc0 sc1
+// (system scope: served by the memory side without a place in the L2) -- the last two only in tuning builds' sweeps
 template <int POLICY = 0>
 LZ4HIP_DEVICE void vm_load16_pred(bool pred, uint64_t addr, u32x4& v)
 {
     const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
     uint64_t saved;
-    if (POLICY == 1)
-        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off nt\n\ts_mov_b64 exec, %[sv]"
-                     : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory");
-    else
-        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
-                     : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory");
+#define LZ4HIP_VM_LOAD(MODS)                                                                                                      \
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off" MODS "\n\ts_mov_b64 exec, %[sv]"       \
+                 : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory")
+    if (POLICY == 1) LZ4HIP_VM_LOAD(" nt");
+    else if (POLICY == 2) LZ4HIP_VM_LOAD(" sc1");
+    else if (POLICY == 3) LZ4HIP_VM_LOAD(" sc0 sc1");
+    else LZ4HIP_VM_LOAD("");
+#undef LZ4HIP_VM_LOAD
 }
 LZ4HIP_DEVICE void vm_store16_pred(bool pred, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
