@@ -28,6 +28,12 @@
 
 namespace lz4hip {
 
+#ifndef LZ4HIP_HC_CTRL_EVERY
+#define LZ4HIP_HC_CTRL_EVERY 8      /* 2 / 4 / 8 / 16: 7.9 / 8.1 / 8.3 / 8.3 GB/s on D2 (profiles/r03/hc_convergent_control_batching_interval.txt) */
+#endif
+constexpr int kHcCtrlEvery = LZ4HIP_HC_CTRL_EVERY;      // (power of two)
+constexpr int kHcCtrlBatchLanes = 16;
+
 enum HcConvState {
     kHsFetch = 0,   // take the next block from the counter
     kHsZero,        // zero the heads, 64 bytes per step
@@ -43,6 +49,8 @@ enum HcConvState {
 };
 
 // One lane = one block at a time; all 64 lanes of the wavefront iterate together until every lane has run out of blocks.
+// (113 VGPRs: four wavefronts per SIMD.  The rate still grows with the residency at 16 wavefronts per CU, but a register budget
+//  for 5 / 6 per SIMD costs 18 / 36 dwords of scratch per lane and is slower: profiles/r03/hc_convergent_more_wavefronts_with_spills.txt)
 template <class HeadT>
 __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned long long* counter, uint8_t* slabs, unsigned long long slab_bytes)
 {
@@ -74,9 +82,36 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
     int zero_at = 0;
     // length counts (kHsFwd / kHsBack)
     int c_n = 0, c_for_rep = 0, c_s = 0, c_r = 0, c_fwd_end = 0;
-    // rolling prefetch of the insert loop: nw == load_u32(in + next) when nw_ok
-    uint32_t nw = 0;
-    int nw_ok = 0;
+    // The insert loop reads the input through a 16-byte register window (bytes [iw_pos, iw_pos + iw_len) of the block): one
+    // 16-byte load per 13 positions instead of a 4-byte load per position -- with a quarter of a million lanes in flight a
+    // line does not survive in any cache between two steps of a lane, so every load is a line across the fabric.
+    Vec16 iw = { { 0, 0, 0, 0 } };
+    int iw_pos = 0, iw_len = 0;
+    // ... and writes the chain through an 8-entry buffer (one aligned 16-byte store per group of 8 positions and per insert
+    // burst instead of a 2-byte store per position).  Only for blocks <= 64 KiB (16-bit heads): the buffer also stores the
+    // group's not-yet-inserted slots, which nobody reads before they are written -- unless slots wrap (position & 0xFFFF).
+    constexpr bool kChainBuf = sizeof(HeadT) == 2;
+    uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
+    int cb_base = 0, cb_dirty = 0;
+    auto iw_has = [&](int p) { return (p >= iw_pos) & (p + 4 <= iw_pos + iw_len); };
+    auto iw_word = [&](int p) -> uint32_t {                           // (iw_has(p))
+        const int o = p - iw_pos, q = o >> 2;
+        const uint32_t lo = q < 2 ? (q == 0 ? iw.w[0] : iw.w[1]) : (q == 2 ? iw.w[2] : iw.w[3]);
+        const uint32_t hi = q < 2 ? (q == 0 ? iw.w[1] : iw.w[2]) : iw.w[3];
+        return wv::alignbyte(hi, lo, (uint32_t)o & 3u);
+    };
+    auto chain_flush = [&]() {
+        if (kChainBuf && cb_dirty) { store_v16((uint8_t*)(chain + cb_base), Vec16{ { cb0, cb1, cb2, cb3 } }); cb_dirty = 0; }
+    };
+    auto chain_put = [&](int p, uint32_t delta) {
+        if (!kChainBuf) { chain[p & 0xFFFF] = (uint16_t)delta; return; }
+        if ((p & ~7) != cb_base) { chain_flush(); cb_base = p & ~7; }
+        const int k = (p & 7) >> 1;
+        const uint32_t keep = (p & 1) ? 0x0000FFFFu : 0xFFFF0000u, val = (p & 1) ? (delta << 16) : delta;
+        cb0 = k == 0 ? (cb0 & keep) | val : cb0; cb1 = k == 1 ? (cb1 & keep) | val : cb1;
+        cb2 = k == 2 ? (cb2 & keep) | val : cb2; cb3 = k == 3 ? (cb3 & keep) | val : cb3;
+        cb_dirty = 1;
+    };
 
     // search request (from the control flow): LZ4HC_InsertAndFindBestMatch / LZ4HC_InsertAndGetWiderMatch
     auto request = [&](int pos, int start_limit, int longest, int match0, int start0_) {
@@ -85,6 +120,7 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
         st = next < pos ? (int)kHsInsert : (int)kHsHead;
     };
 
+    int it = 0;
     for (;;) {
         // ================= rare: block hand-out and the control flow between two searches =================
         if (st == kHsFetch) {
@@ -96,14 +132,21 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
                 if (sizeof(HeadT) == 2 && n > 65536) { b.result[blk] = -2000000002; st = kHsFetch; }   // LZ4HIP_E_ARGUMENT: launch reserved 16-bit heads only
                 else {
                     mflimit = n - kMfLimit; matchlimit = n - kLastLiterals;
-                    ip = 1; anchor = 0; op = 0; next = 1; nw_ok = 0;                     // lz4hc.c:334, :581
+                    ip = 1; anchor = 0; op = 0; next = 1; iw_len = 0;                    // lz4hc.c:334, :581
+                    cb0 = 0xFFFFu; cb1 = cb2 = cb3 = 0; cb_base = 0; cb_dirty = 0;       // (slot 0 keeps its 0xFFFF through the flushes of group 0)
                     zero_at = 0; st = kHsZero;
                 }
             }
         }
         if (!wv::any(st != kHsExit)) break;
 
-        if (st == kHsCtrl) {
+        // The control flow is long (a sequence emit is a few hundred instructions with loops of its own) and a lane needs it
+        // only every dozen steps: run it for all waiting lanes at once, when a quarter of the wavefront is waiting or every
+        // eighth iteration, instead of in every iteration for the handful of lanes that have just finished a search
+        // (6.7 -> 8.3 GB/s on D2).
+        it++;
+        const bool ctrl_now = wv::popc64(wv::ballot(st == kHsCtrl)) >= kHcCtrlBatchLanes || (it & (kHcCtrlEvery - 1)) == 0;
+        if (ctrl_now && st == kHsCtrl) {
             // `pc`: 0 after best, 1 after the first wider search, 2 after the second one, 3 top of the main loop,
             // 4 _Search2, 5 _Search3 (lz4hc.c:584-727); leaves with a search requested (st set) or the block finished
             int pc = phase;
@@ -218,17 +261,22 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
         // Every load of the step is issued first -- eight load instructions, each carrying the lanes whose state needs it, at
         // per-lane addresses -- then the states are processed on what came back: ONE fabric round trip per iteration whatever
         // mix of states the wavefront is in (a state-by-state body made the round trips of the states add up).
-        if (st == kHsHead && !s_wok && nw_ok && next == s_ip) { s_word = nw; s_wok = 1; }   // (the insert loop's prefetch is the search word)
+        if (st == kHsHead && !s_wok && iw_has(s_ip)) { s_word = iw_word(s_ip); s_wok = 1; }   // (the insert loop's window usually holds the search word)
         const bool inI = st == kHsInsert, inH = st == kHsHead, inR = st == kHsRep, inP = st == kHsHop, inF = st == kHsFwd,
                    inB = st == kHsBack, inL = st == kHsRepl;
-        const bool ins_go = inI & (nw_ok != 0), head_go = inH & (s_wok != 0);
+        const bool ins_go = inI & iw_has(next), head_go = inH & (s_wok != 0);
+        // the window has to move when the position after this one is not in it any more (or this one is not: then this step only loads)
+        const int iw_want = ins_go ? next + 1 : next;
+        const bool iw_load = inI & (!ins_go | ((next + 1 <= s_ip) & !iw_has(next + 1)));
+        const bool iw_full = iw_want + 16 <= n;                      // (near the end of a block: 4 bytes at a time)
+        const uint32_t ins_word = ins_go ? iw_word(next) : 0u;
         // Fwd: 16-byte pieces while they fit below matchlimit; Back: 4 bytes at a time while both sides have them
         const int f_a = s_ip + 4 + c_n, f_b = s_ref + 4 + c_n;
         const bool fwd16 = inF & (f_a + 16 <= matchlimit);
         const bool back4 = inB & (c_s - s_limit >= 4) & (c_r >= 4);
         const bool repl_head = inL & (s_repl < 0) & !(c_s < c_r - s_delta);      // (s_repl < 0: the walk is set up, see below)
         // (1) head of a bucket: insert / search start
-        const uint32_t hsh = hash15(ins_go ? nw : s_word);
+        const uint32_t hsh = hash15(ins_go ? ins_word : s_word);
         HeadT v_head = 0;
         if (ins_go | head_go) v_head = head[hsh];
         // (2) chain link of the candidate
@@ -238,8 +286,8 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
         //     start (backward extension), the word to hash (repeat fill)
         uint32_t v_w = 0;
         {
-            const int aw = inI ? (ins_go ? next + 1 : next) : inH ? s_ip : (inR | inP) ? s_ref : inB ? c_s - 4 : c_s;
-            const bool need = (inI & (!ins_go | (next + 1 <= s_ip))) | (inH & !head_go) | inR | inP | back4 | repl_head;
+            const int aw = inI ? iw_want : inH ? s_ip : (inR | inP) ? s_ref : inB ? c_s - 4 : c_s;
+            const bool need = (iw_load & !iw_full) | (inH & !head_go) | inR | inP | back4 | repl_head;
             if (need) v_w = load_u32(in + aw);
         }
         // (4) 4 bytes before the candidate's start (backward extension)
@@ -253,7 +301,7 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
         Vec16 v_y = { { 0, 0, 0, 0 } }, v_x = { { 0, 0, 0, 0 } };
         {
             const bool fwd_ok_now = s_ip + 4 + 16 <= matchlimit;
-            if (fwd16 | (head_go & fwd_ok_now)) v_y = load_v16(in + (inF ? f_b : s_ip + 4));
+            if (fwd16 | (head_go & fwd_ok_now) | (iw_load & iw_full)) v_y = load_v16(in + (inF ? f_b : inI ? iw_want : s_ip + 4));
             if (fwd16 & !((c_n == 0) & (s_fwd_ok != 0))) v_x = load_v16(in + f_a);
         }
 
@@ -268,15 +316,17 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
                 phase = 3; st = kHsCtrl;                             // (blocks too short for any match go straight to the last literals)
             }
         } else if (inI) {                                            // lz4hc.c:358-373, one position
-            if (!ins_go) { nw = v_w; nw_ok = 1; }
-            else {
+            if (ins_go) {
                 const int p = next, prev = (int)v_head;
                 const uint32_t delta = (p < prev || p - prev > kMaxDistance) ? (uint32_t)kMaxDistance : (uint32_t)(p - prev);
-                chain[p & 0xFFFF] = (uint16_t)delta;
+                chain_put(p, delta);
                 head[hsh] = (HeadT)p;
                 next = p + 1;
-                nw = v_w; nw_ok = next <= s_ip;                      // (prefetched while next + 1 <= s_ip held)
-                if (next >= s_ip) st = kHsHead;
+                if (next >= s_ip) { chain_flush(); st = kHsHead; }   // (the walk that follows may read what this burst wrote)
+            }
+            if (iw_load) {
+                if (iw_full) { iw = v_y; iw_len = 16; } else { iw = Vec16{ { v_w, 0, 0, 0 } }; iw_len = 4; }
+                iw_pos = iw_want;
             }
         } else if (inH) {
             if (!head_go) { s_word = v_w; s_wok = 1; }
@@ -356,10 +406,10 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
             if (s_repl > 0) { c_s = s_ip; c_r = s_ip + s_repl - 3; s_repl = -1; }   // first visit: set up the walk (its loads come next iteration)
             else {
                 const int q = c_s, end = c_r;
-                chain[q & 0xFFFF] = (uint16_t)s_delta;
+                chain_put(q, (uint32_t)s_delta);
                 if (!(q < end - s_delta)) head[hash15(v_w)] = (HeadT)q;   // do { chain; head } while (q < end): runs at least once
                 c_s = q + 1;
-                if (!(q < end - s_delta) && c_s >= end) { next = end; nw_ok = 0; s_repl = 0; st = kHsCtrl; }
+                if (!(q < end - s_delta) && c_s >= end) { chain_flush(); next = end; s_repl = 0; st = kHsCtrl; }
             }
         }
     }

@@ -19,13 +19,17 @@ for dist in dists:
         _lib.tuning_set("hc_gen", gen); _lib.tuning_set("hc_waves_per_cu", wpc)
         batch.encode(raw[:16384], batch.BLOCK, comp[:16384], batch.BOUND, hc=True, result=clen[:16384])   # workspace for this residency
         torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True, result=clen); b.record(); b.synchronize()
-        t = a.elapsed_time(b)
+        ts = []
+        for _ in range(2):                # (the first pass of a residency also allocates its workspace inside the launch call)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True, result=clen); b.record(); b.synchronize()
+            ts.append(a.elapsed_time(b))
+        t = min(ts)
+        passes = ", ".join("%.0f" % x for x in ts)
         sig = (batch.checksum(comp, clen).cpu().numpy().copy(), clen.cpu().numpy().copy())
         same = None if ref is None else bool((sig[0] == ref[0]).all() and (sig[1] == ref[1]).all())
         if ref is None:
             ref = sig
-        print(f"dist={dist} blocks={n} hc_gen={gen} waves/CU={wpc}: {n * 65536 / t / 1e6:7.3f} GB/s  {t:9.1f} ms  ratio {float(clen.double().sum()) / (n * 65536):.4f}  same bytes as first config: {same}", flush=True)
+        print(f"dist={dist} blocks={n} hc_gen={gen} waves/CU={wpc}: {n * 65536 / t / 1e6:7.3f} GB/s  {t:9.1f} ms (passes: {passes})  ratio {float(clen.double().sum()) / (n * 65536):.4f}  same bytes as first config: {same}", flush=True)
     del raw, comp
     torch.cuda.empty_cache()
