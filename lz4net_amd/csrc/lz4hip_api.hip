@@ -569,10 +569,14 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
         max_dst = dc > max_dst ? dc : max_dst;
     }
     const size_t s_stride = align_up((size_t)max_src + 16, 16), d_stride = align_up((size_t)max_dst + 16, 16);
-    // slice size: a small batch goes in one piece; a large one in about 6 slices (LZ4HIP_HOST_SLICES; profiles/r02/host_slices_sweep.txt) of 32 MiB .. 512 MiB
-    // of rows each
+    // slice size: a small batch goes in one piece; a large one in about 6 slices (knob host_slices; profiles/r02/host_slices_sweep.txt) of
+    // 32 MiB .. 512 MiB of rows each
     const size_t row_bytes = s_stride + d_stride;
-    const int want_slices = knob(kKnobHostSlices) > 0 ? knob(kKnobHostSlices) : 6;
+    // slices: the kernels of a slice take milliseconds however few blocks it has (a 64 KiB block of short sequences needs 2.6 ms
+    // in the wavefront mapping), so small batches are cut less: 1 slice up to ~3 k blocks, 2 at 4 k, 6 from 12 k
+    // (profiles/r03/host_slices_by_batch_size.txt: 4 096 blocks 19.4 GB/s with 2 slices, 14.7-18.4 with 6-8)
+    const int auto_slices = (int)(n / 2048 < 1 ? 1 : (n / 2048 > 6 ? 6 : n / 2048));
+    const int want_slices = knob(kKnobHostSlices) > 0 ? knob(kKnobHostSlices) : auto_slices;
     int64_t per_slice = (n + want_slices - 1) / want_slices;
     const int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
     per_slice = per_slice < lo ? lo : per_slice;

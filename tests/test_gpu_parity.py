@@ -274,6 +274,7 @@ def test_host_batch_many_slices_and_layouts(gpu, oracle):
     b = _lib.Batch(src=src.ctypes.data, src_off=src_off.ctypes.data, src_stride=0, src_len=lens.ctypes.data,
                    dst=dst.ctypes.data, dst_off=dst_off.ctypes.data, dst_stride=0, dst_cap=caps.ctypes.data,
                    dst_cap_all=0, src_len_all=0, result=res.ctypes.data, n_blocks=n)
+    _lib.tuning_set("host_slices", 5)                            # (a batch this small would go in one piece by default)
     _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), 0))
     for i in list(range(16)) + list(range(16, n, 97)) + [n - 1]:
         ret, out = oracle.compress_raw(raw_rows[i, :sizes[i]], int(caps[i]))
@@ -287,10 +288,15 @@ def test_host_batch_many_slices_and_layouts(gpu, oracle):
                    dst=back.ctypes.data, dst_off=None, dst_stride=back.strides[0], dst_cap=lens.ctypes.data,
                    dst_cap_all=0, src_len_all=0, result=used.ctypes.data, n_blocks=n)
     _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(d), 1))
+    _lib.tuning_set("host_slices", 0)
     assert (used == res).all()
     for i in range(n):
         assert np.array_equal(back[i, :sizes[i]], raw_rows[i, :sizes[i]]), i
         assert (back[i, sizes[i]:] == 0x5A).all(), i
+    # ... and with the default cut (one piece for a batch of this size)
+    used[:] = 0; back[:] = 0x5A
+    _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(d), 1))
+    assert (used == res).all() and all(np.array_equal(back[i, :sizes[i]], raw_rows[i, :sizes[i]]) for i in range(0, n, 13))
 
 
 def test_host_entry_points_from_several_threads(gpu, oracle):
