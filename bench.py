@@ -463,7 +463,7 @@ def main():
                 "decode_GBps": rate_big, "blocks": m_big, "decode_GBps_small_batch": rate_small, "blocks_small_batch": m_small,
                 "ok": ok_big and ok_small,
                 "note": "lz4hip_decode_batch_host on pageable host arrays: gather + H2D + kernels + D2H + scatter, best of 3 "
-                        "(reported beside, never as, `value`); a batch is cut into ~6 slices whose copies and kernels overlap",
+                        "(reported beside, never as, `value`); a batch is cut into 1-6 slices (one per ~2048 blocks) whose copies and kernels overlap",
             }
 
     if rank != 0:
