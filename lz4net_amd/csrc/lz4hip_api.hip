@@ -13,6 +13,7 @@
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
+#include "lz4hip_hc_nat.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
@@ -52,7 +53,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
     { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
     { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
-    { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default, 1 lz4hip_hc_lane.hpp, 2 lz4hip_hc_conv.hpp (convergent state machine)
+    { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default, 1 lz4hip_hc_lane.hpp (tuning builds), 2 lz4hip_hc_conv.hpp, 3 lz4hip_hc_nat.hpp (no insert loop; blocks <= 64 KiB)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -76,7 +77,7 @@ constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
-constexpr int kHcLaneGeneration = 2;
+constexpr int kHcLaneGeneration = 3;           // blocks <= 64 KiB; larger ones: 2
 
 int fail(int code, const std::string& what)
 {
@@ -266,19 +267,43 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         int rc = lease_begin(g_hc_ws, stream, lease);
         if (rc) return rc;
         if (lane_per_block) {
+            int hc_gen = knob(kKnobHcGen) ? knob(kKnobHcGen) : kHcLaneGeneration;
+            if (hc_gen == 3 && !small) hc_gen = 2;                    // lz4hip_hc_nat.hpp is for blocks <= 64 KiB
             const size_t slab = small ? kHcLaneSlab16 : kHcLaneSlab32;
             int wpc = knob(kKnobHcWavesPerCu) > 0 ? knob(kKnobHcWavesPerCu) : kHcLaneWavesPerCu;
             void* ws = nullptr;
-            int64_t groups = 0;
+            int64_t groups = 0, chunk = 0;
             for (; wpc >= 1; wpc /= 2) {
                 groups = (int64_t)cus * wpc;
                 if (knob(kKnobHcGroups) > 0) groups = knob(kKnobHcGroups);
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-                if (lease_reserve(lease, (size_t)groups * 64 * slab + 256) == 0) { ws = lease.p; break; }
+                // generation 3: one chain table per block of a chunk (a chunk = one block per resident lane, at least 4096)
+                chunk = groups * 64 < 4096 ? 4096 : groups * 64;
+                if (chunk > d.n_blocks) chunk = d.n_blocks;
+                const size_t bytes = hc_gen == 3 ? (size_t)chunk * kHcNatChainBytes : (size_t)groups * 64 * slab;
+                if (lease_reserve(lease, bytes + 256) == 0) { ws = lease.p; break; }
+            }
+            if (ws && hc_gen == 3) {
+                // lz4hip_hc_nat.hpp: per chunk, the chain builder (one wavefront per block, heads in LDS), then the lane kernel
+                for (int64_t first = 0; first < d.n_blocks; first += chunk) {
+                    const int64_t cnt = d.n_blocks - first < chunk ? d.n_blocks - first : chunk;
+                    int64_t g = (cnt + 63) / 64 < groups ? (cnt + 63) / 64 : groups;
+                    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+                    hipLaunchKernelGGL(hc_nat_chain_kernel, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                    HIP_TRY(hipGetLastError());
+                    if (wpc > 16)
+                        hipLaunchKernelGGL(encode_hc_nat_kernel<5>, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
+                                           (unsigned long long*)ws, (uint8_t*)ws + 256);
+                    else
+                        hipLaunchKernelGGL(encode_hc_nat_kernel<4>, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
+                                           (unsigned long long*)ws, (uint8_t*)ws + 256);
+                    HIP_TRY(hipGetLastError());
+                }
+                count_dispatch(LZ4HIP_K_HC_LANE);
+                return lease_end(lease, stream);
             }
             if (ws) {
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                const int hc_gen = knob(kKnobHcGen) ? knob(kKnobHcGen) : kHcLaneGeneration;
                 if (hc_gen == 2 && small)
                     hipLaunchKernelGGL(encode_hc_conv_kernel<uint16_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                        (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);

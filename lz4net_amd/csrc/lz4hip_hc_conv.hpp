@@ -140,122 +140,7 @@ __global__ void __launch_bounds__(64) encode_hc_conv_kernel(Batch b, unsigned lo
         }
         if (!wv::any(st != kHsExit)) break;
 
-        // The control flow is long (a sequence emit is a few hundred instructions with loops of its own) and a lane needs it
-        // only every dozen steps: run it for all waiting lanes at once, when a quarter of the wavefront is waiting or every
-        // eighth iteration, instead of in every iteration for the handful of lanes that have just finished a search
-        // (6.7 -> 8.3 GB/s on D2).
-        it++;
-        const bool ctrl_now = wv::popc64(wv::ballot(st == kHsCtrl)) >= kHcCtrlBatchLanes || (it & (kHcCtrlEvery - 1)) == 0;
-        if (ctrl_now && st == kHsCtrl) {
-            // `pc`: 0 after best, 1 after the first wider search, 2 after the second one, 3 top of the main loop,
-            // 4 _Search2, 5 _Search3 (lz4hc.c:584-727); leaves with a search requested (st set) or the block finished
-            int pc = phase;
-            bool failed = false, finished = false;
-            auto emit = [&](int mlen, int mref) -> bool {                 // LZ4_encodeSequence, lz4hc.c:521-550 (see lane_hc_emit)
-                const int ll = ip - anchor;
-                const int token_at = op++;
-                if (op + ll + 8 + (ll >> 8) > cap) return false;                   // lz4hc.c:529
-                uint32_t token = ll >= 15 ? 0xF0u : (uint32_t)(ll << 4);
-                if (ll >= 15) op += lane_put_length(out + op, ll - 15);
-                lane_copy(out + op, in + anchor, ll);
-                op += ll;
-                const uint32_t o = (uint32_t)(ip - mref) & 0xFFFFu;
-                out[op] = (uint8_t)o; out[op + 1] = (uint8_t)(o >> 8);
-                op += 2;
-                const int extra = mlen - kMinMatch;
-                if (op + 6 + (ll >> 8) > cap) return false;                        // lz4hc.c:541 tests the LITERAL length
-                if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return false;   // never write past cap (see lz4hip_hc.hpp)
-                token |= extra >= 15 ? 15u : (uint32_t)extra;
-                out[token_at] = (uint8_t)token;
-                if (extra >= 15) op += lane_put_length(out + op, extra - 15);
-                ip += mlen;
-                anchor = ip;
-                return true;
-            };
-            for (;;) {
-                if (pc == 3) {                                       // while (ip < mflimit), lz4hc.c:584
-                    if (ip < mflimit) { phase = 0; request(ip, ip, 0, ref, 0); break; }
-                    finished = true; break;
-                } else if (pc == 0) {                                // ml = best match at ip
-                    ml = s_len; ref = s_match;
-                    if (!ml) { ip++; pc = 3; continue; }
-                    start0 = ip; ref0 = ref; ml0 = ml;
-                    pc = 4;
-                } else if (pc == 4) {                                // _Search2, lz4hc.c:594-597
-                    if (ip + ml < mflimit) { phase = 1; request(ip + ml - 2, ip + 1, ml, ref2, start2); break; }
-                    s_len = ml; s_match = ref2; s_start = start2;
-                    pc = 1;
-                } else if (pc == 1) {                                // lz4hc.c:599-622
-                    ml2 = s_len; ref2 = s_match; start2 = s_start;
-                    if (ml2 == ml) { if (!emit(ml, ref)) { failed = true; break; } pc = 3; continue; }
-                    if (start0 < ip && start2 < ip + ml0) { ip = start0; ref = ref0; ml = ml0; }
-                    if (start2 - ip < 3) { ml = ml2; ip = start2; ref = ref2; pc = 4; continue; }
-                    pc = 5;
-                } else if (pc == 5) {                                // _Search3, lz4hc.c:624-641
-                    if (start2 - ip < kHcOptimalMl) {
-                        int new_ml = ml > kHcOptimalMl ? kHcOptimalMl : ml;
-                        if (ip + new_ml > start2 + ml2 - kMinMatch) new_ml = (start2 - ip) + ml2 - kMinMatch;
-                        const int corr = new_ml - (start2 - ip);
-                        if (corr > 0) { start2 += corr; ref2 += corr; ml2 -= corr; }
-                    }
-                    if (start2 + ml2 < mflimit) { phase = 2; request(start2 + ml2 - 3, start2, ml2, ref3, start3); break; }
-                    s_len = ml2; s_match = ref3; s_start = start3;
-                    pc = 2;
-                } else {                                             // pc == 2: lz4hc.c:643-727
-                    ml3 = s_len; ref3 = s_match; start3 = s_start;
-                    if (ml3 == ml2) {
-                        if (start2 < ip + ml) ml = start2 - ip;
-                        if (!emit(ml, ref)) { failed = true; break; }
-                        ip = start2;
-                        if (!emit(ml2, ref2)) { failed = true; break; }
-                        pc = 3; continue;
-                    }
-                    if (start3 < ip + ml + 3) {
-                        if (start3 >= ip + ml) {
-                            if (start2 < ip + ml) {
-                                const int corr = ip + ml - start2;
-                                start2 += corr; ref2 += corr; ml2 -= corr;
-                                if (ml2 < kMinMatch) { start2 = start3; ref2 = ref3; ml2 = ml3; }
-                            }
-                            if (!emit(ml, ref)) { failed = true; break; }
-                            ip = start3; ref = ref3; ml = ml3;
-                            start0 = start2; ref0 = ref2; ml0 = ml2;
-                            pc = 4; continue;
-                        }
-                        start2 = start3; ref2 = ref3; ml2 = ml3;
-                        pc = 5; continue;
-                    }
-                    if (start2 < ip + ml) {
-                        if (start2 - ip < 15) {
-                            if (ml > kHcOptimalMl) ml = kHcOptimalMl;
-                            if (ip + ml > start2 + ml2 - kMinMatch) ml = (start2 - ip) + ml2 - kMinMatch;
-                            const int corr = ml - (start2 - ip);
-                            if (corr > 0) { start2 += corr; ref2 += corr; ml2 -= corr; }
-                        } else {
-                            ml = start2 - ip;
-                        }
-                    }
-                    if (!emit(ml, ref)) { failed = true; break; }
-                    ip = start2; ref = ref2; ml = ml2;
-                    start2 = start3; ref2 = ref3; ml2 = ml3;
-                    pc = 5;
-                }
-            }
-            if (failed) { b.result[blk] = 0; st = kHsFetch; }
-            else if (finished) {                                     // last literals, lz4hc.c:730-738
-                const int run = n - anchor;
-                int r = 0;
-                if (op + run + 1 + (run + 255 - 15) / 255 <= cap) {
-                    out[op++] = (uint8_t)(run >= 15 ? 0xF0 : (run << 4));
-                    if (run >= 15) op += lane_put_length(out + op, run - 15);
-                    lane_copy(out + op, in + anchor, run);
-                    op += run;
-                    r = op;
-                }
-                b.result[blk] = r;
-                st = kHsFetch;
-            }
-        }
+#include "lz4hip_hc_parse.inc"
 
         // ================= one memory step of the state each lane is in =================
         // Every load of the step is issued first -- eight load instructions, each carrying the lanes whose state needs it, at

@@ -16,7 +16,7 @@ def build(starved: bool = False) -> str:
     load to 2 pieces per round, so that lanes run out of input) -- the rare states of the lane decoder (a lane that
     cannot append, a far-match chunk fetched but not consumed) become the common ones."""
     so = SO.replace(".so", "_starved.so") if starved else SO
-    deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "*.hpp")) + \
+    deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "*.hpp")) + \
         [os.path.join(HERE, "emu_kernels.cpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         flags = ["-DLZ4HIP_HAVE_HC"] if os.path.exists(os.path.join(CSRC, "lz4hip_hc.hpp")) else []

@@ -17,6 +17,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #include "lz4hip_hc.hpp"
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
+#include "lz4hip_hc_nat.hpp"
 #endif
 
 using namespace lz4hip;
@@ -188,6 +189,22 @@ void emu_encode_hc_conv(const uint8_t* src, int64_t src_stride, const int32_t* s
     uint8_t* slabs = ws.data() + 256;
     if (heads32) simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_conv_kernel<uint32_t>(b, counter, slabs, (unsigned long long)slab); });
     else         simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_conv_kernel<uint16_t>(b, counter, slabs, (unsigned long long)slab); });
+}
+#endif
+
+#ifdef LZ4HIP_HAVE_HC
+// LZ4HC without the insert loop (lz4hip_hc_nat.hpp): the chain builder over every block, then the lane kernel
+void emu_encode_hc_nat(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                       int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)n * kHcNatChainBytes, 0x5A);      // poisoned
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* chains = ws.data() + 256;
+    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel(b, 0, chains); });
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_nat_kernel<4>(b, 0, (long long)n, counter, chains); });
 }
 #endif
 

@@ -526,3 +526,67 @@ def test_hc_lane_slab_reuse(gpu, oracle):
         w = oracle.compress(a, hc=True)
         assert res[i] == len(w), (i, a.size, res[i], len(w))
         assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+
+
+def _nat_blocks(oracle, n, seed, big_every=40):
+    """Blocks <= 64 KiB that stress the exactness argument of lz4hip_hc_nat.hpp: short-period runs, tiny alphabets, copies of
+    earlier content, runs with single disturbed bytes, plus fuzzer-style and record-like rows."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for i in range(n):
+        mode = i % 6
+        sz = int(rng.integers(13, 6000)) if i % big_every else 65536 - int(rng.integers(0, 3000))
+        if mode == 0:
+            row = rng.integers(0, int(rng.integers(2, 4)), sz).astype(np.uint8)
+        elif mode == 1:
+            row = rng.integers(0, 256, sz).astype(np.uint8)
+            pos = 0
+            while pos < sz:
+                per, ln = int(rng.integers(1, 6)), int(rng.integers(4, 300))
+                seg = np.tile(rng.integers(0, 3, per).astype(np.uint8), ln // per + 2)[:ln]
+                e = min(sz, pos + ln)
+                row[pos:e] = seg[:e - pos]
+                pos = e + int(rng.integers(0, 12))
+        elif mode == 2:
+            row = oracle.gen(2, 300 + seed, i, 1).reshape(-1)[:sz].copy()
+            row[sz // 2:] = row[:sz - sz // 2]
+        elif mode == 3:
+            row = oracle.gen(3, 300 + seed, i, 1).reshape(-1)[:sz].copy()
+            row[: sz // 3] = row[0]
+        elif mode == 4:
+            row = np.full(sz, int(rng.integers(0, 256)), np.uint8)
+            for _ in range(int(rng.integers(0, 40))):
+                row[int(rng.integers(0, sz))] = int(rng.integers(0, 256))
+        else:
+            row = oracle.gen(2, 400 + seed, i, 1).reshape(-1)[:sz].copy()
+        blocks.append(row)
+    return blocks
+
+
+@pytest.mark.parametrize("hc_gen", [3, 2], ids=["precomputed-chains", "convergent"])
+def test_hc_lane_small_blocks_many_per_lane(gpu, oracle, hc_gen):
+    """The LZ4HC lane kernels for blocks <= 64 KiB with ONE wavefront in the grid: 640 blocks, ten per lane.  Generation 3
+    (lz4hip_hc_nat.hpp, the default) builds the natural chains of the whole chunk first; generation 2 is the state machine
+    with the insert loop.  EVERY block is compared with the oracle."""
+    from lz4net_amd import _lib
+    blocks = _nat_blocks(oracle, 640, 5)
+    with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1, hc_gen=hc_gen):
+        res, dst = gpu.encode(blocks, hc=True)
+    for i, a in enumerate(blocks):
+        w = oracle.compress(a, hc=True)
+        assert res[i] == len(w), (i, a.size, res[i], len(w))
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+
+
+def test_hc_precomputed_chains_several_chunks(gpu, oracle):
+    """lz4hip_hc_nat.hpp over a batch larger than its chunk (4096 chain tables with one wavefront in the grid): 9000 short blocks
+    in ONE device batch = three rounds of chain builder + lane kernel on the same tables."""
+    from lz4net_amd import _lib
+    blocks = _nat_blocks(oracle, 9000, 9, big_every=3000)
+    blocks = [b[:2500] for b in blocks]
+    with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1, host_slices=1):
+        res, dst = gpu.encode(blocks, hc=True)
+    for i, a in enumerate(blocks):
+        w = oracle.compress(a, hc=True)
+        assert res[i] == len(w), (i, a.size, res[i], len(w))
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size)

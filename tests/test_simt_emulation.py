@@ -210,6 +210,72 @@ def test_encode_hc_limited_output(oracle, lane):
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
+def test_encode_hc_nat_bit_exact(oracle):
+    """LZ4HC over precomputed natural chains (lz4hip_hc_nat.hpp: chain builder + lane kernel without the insert loop)."""
+    blocks = _blocks(oracle, sizes=(0, 1, 4, 5, 12, 13, 14, 64, 65, 66, 300, 4096, 20000, 65536))
+    blocks.append(oracle.gen(3, 3, 0, 1, 65536)[0])
+    blocks.append(np.zeros(65536, np.uint8))
+    blocks.append(np.tile(np.frombuffer(b"abc", np.uint8), 21846)[:65536].copy())
+    res, dst = emu.encode(blocks, hc=True, nat=True, groups=2)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+    # a block > 64 KiB is refused by this kernel (the library launches lz4hip_hc_conv.hpp for such batches)
+    res, dst = emu.encode([oracle.gen(2, 3, 0, 2).reshape(-1)[:70000].copy(), blocks[10]], hc=True, nat=True, groups=1)
+    assert res[0] == -2000000002 and res[1] == len(oracle.compress(blocks[10], hc=True))
+
+
+def test_encode_hc_nat_limited_output(oracle):
+    blocks = _blocks(oracle, sizes=(13, 300, 4096))
+    lens = [len(oracle.compress(a, hc=True)) for a in blocks]
+    for delta in (0, -1, -7):
+        caps = [max(l + delta, 0) for l in lens]
+        res, dst = emu.encode(blocks, caps=caps, hc=True, nat=True, groups=1)
+        for i, a in enumerate(blocks):
+            want = oracle.compress_raw(a, caps[i], hc=True)[0]
+            assert res[i] == want, (i, delta, res[i], want)
+            assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
+
+
+def test_encode_hc_nat_repeats_and_collisions(oracle):
+    """What the exactness argument of lz4hip_hc_nat.hpp rests on: runs of period 1-5 (the repeat optimisation rewires their
+    chains and skips their head updates), tiny alphabets (same words everywhere), copies of earlier content, runs with single
+    disturbed bytes -- ONE wavefront, five blocks per lane, every block the oracle's bytes."""
+    rng = np.random.default_rng(23)
+    blocks = []
+    for i in range(320):
+        mode = i % 5
+        sz = int(rng.integers(13, 6000)) if i % 40 else 65536 - int(rng.integers(0, 3000))
+        if mode == 0:
+            row = rng.integers(0, int(rng.integers(2, 4)), sz).astype(np.uint8)
+        elif mode == 1:
+            row = rng.integers(0, 256, sz).astype(np.uint8)
+            pos = 0
+            while pos < sz:
+                per, ln = int(rng.integers(1, 6)), int(rng.integers(4, 300))
+                seg = np.tile(rng.integers(0, 3, per).astype(np.uint8), ln // per + 2)[:ln]
+                e = min(sz, pos + ln)
+                row[pos:e] = seg[:e - pos]
+                pos = e + int(rng.integers(0, 12))
+        elif mode == 2:
+            row = oracle.gen(2, 300 + i, i, 1).reshape(-1)[:sz].copy()
+            row[sz // 2:] = row[:sz - sz // 2]
+        elif mode == 3:
+            row = oracle.gen(3, 300 + i, i, 1).reshape(-1)[:sz].copy()
+            row[: sz // 3] = row[0]
+        else:
+            row = np.full(sz, int(rng.integers(0, 256)), np.uint8)
+            for _ in range(int(rng.integers(0, 40))):
+                row[int(rng.integers(0, sz))] = int(rng.integers(0, 256))
+        blocks.append(row)
+    res, dst = emu.encode(blocks, hc=True, nat=True, groups=1)
+    for i, a in enumerate(blocks):
+        want = oracle.compress(a, hc=True)
+        assert res[i] == len(want), (i, a.size, res[i], len(want))
+        assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
+
+
 def test_encode_hc_lane_slab_reuse(oracle):
     """The LZ4HC lane kernel re-zeroes its heads per block, sets chain[0] and leaves the rest of the previous block's chain
     (and, after a block > 64 KiB, its 32-bit heads where the 16-bit layout has its chain) in place, relying on every slot
