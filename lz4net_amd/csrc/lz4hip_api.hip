@@ -14,6 +14,7 @@
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
 #include "lz4hip_hc_nat.hpp"
+#include "lz4hip_hc_lcp.hpp"
 #include "lz4hip_synth.hpp"
 
 #include "../../include/lz4hip.h"
@@ -43,7 +44,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -54,6 +55,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
     { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
     { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default, 1 lz4hip_hc_lane.hpp (tuning builds), 2 lz4hip_hc_conv.hpp, 3 lz4hip_hc_nat.hpp (no insert loop; blocks <= 64 KiB)
+    { "hc_ctrl_every", "LZ4HIP_HC_CTRL_EVERY", false }, { "hc_ctrl_lanes", "LZ4HIP_HC_CTRL_LANES", false },   // lz4hip_hc_lcp.hpp: control-flow batching (0 default)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -268,7 +270,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         if (rc) return rc;
         if (lane_per_block) {
             int hc_gen = knob(kKnobHcGen) ? knob(kKnobHcGen) : kHcLaneGeneration;
-            if (hc_gen == 3 && !small) hc_gen = 2;                    // lz4hip_hc_nat.hpp is for blocks <= 64 KiB
+            if (hc_gen >= 3 && !small) hc_gen = 2;                    // lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp are for blocks <= 64 KiB
             const size_t slab = small ? kHcLaneSlab16 : kHcLaneSlab32;
             int wpc = knob(kKnobHcWavesPerCu) > 0 ? knob(kKnobHcWavesPerCu) : kHcLaneWavesPerCu;
             void* ws = nullptr;
@@ -277,26 +279,40 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 groups = (int64_t)cus * wpc;
                 if (knob(kKnobHcGroups) > 0) groups = knob(kKnobHcGroups);
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-                // generation 3: one chain table per block of a chunk (a chunk = one block per resident lane, at least 4096)
+                // generation 3: one chain table per block of a chunk; a chunk = at most one block per resident lane (but at least
+                // 4096), the batch cut into equal chunks (a short last chunk would run at a fraction of the residency)
                 chunk = groups * 64 < 4096 ? 4096 : groups * 64;
-                if (chunk > d.n_blocks) chunk = d.n_blocks;
-                const size_t bytes = hc_gen == 3 ? (size_t)chunk * kHcNatChainBytes : (size_t)groups * 64 * slab;
+                const int64_t n_chunks = (d.n_blocks + chunk - 1) / chunk;
+                chunk = ((d.n_blocks + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+                const size_t bytes = hc_gen == 4 ? (size_t)chunk * kHcLcpTableBytes : hc_gen == 3 ? (size_t)chunk * kHcNatChainBytes : (size_t)groups * 64 * slab;
                 if (lease_reserve(lease, bytes + 256) == 0) { ws = lease.p; break; }
             }
-            if (ws && hc_gen == 3) {
-                // lz4hip_hc_nat.hpp: per chunk, the chain builder (one wavefront per block, heads in LDS), then the lane kernel
+            if (ws && hc_gen >= 3) {
+                // lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp: per chunk, the table builders (one workgroup per block), then the lane kernel
+                if (hc_gen == 4) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)hc_lcp_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHcLcpFillLdsBytes));
+                    HIP_TRY(hipFuncSetAttribute((const void*)hc_nat_chain_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kHcNatLdsBytes));
+                } else HIP_TRY(hipFuncSetAttribute((const void*)hc_nat_chain_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kHcNatLdsBytes));
                 for (int64_t first = 0; first < d.n_blocks; first += chunk) {
                     const int64_t cnt = d.n_blocks - first < chunk ? d.n_blocks - first : chunk;
                     int64_t g = (cnt + 63) / 64 < groups ? (cnt + 63) / 64 : groups;
                     HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                    hipLaunchKernelGGL(hc_nat_chain_kernel, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
-                    HIP_TRY(hipGetLastError());
-                    if (wpc > 16)
-                        hipLaunchKernelGGL(encode_hc_nat_kernel<5>, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
+                    if (hc_gen == 4) {
+                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint32_t>, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                        HIP_TRY(hipGetLastError());
+                        hipLaunchKernelGGL(hc_lcp_fill_kernel, dim3((unsigned)cnt), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                        HIP_TRY(hipGetLastError());
+                        int every = knob(kKnobHcCtrlEvery) > 0 ? knob(kKnobHcCtrlEvery) : kHcCtrlEvery;
+                        while (every & (every - 1)) every &= every - 1;          // (a power of two)
+                        const int lanes = knob(kKnobHcCtrlLanes) > 0 ? knob(kKnobHcCtrlLanes) : kHcCtrlBatchLanes;
+                        hipLaunchKernelGGL(encode_hc_lcp_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
+                                           (unsigned long long*)ws, (uint8_t*)ws + 256, every, lanes);
+                    } else {
+                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                        HIP_TRY(hipGetLastError());
+                        hipLaunchKernelGGL(encode_hc_nat_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
                                            (unsigned long long*)ws, (uint8_t*)ws + 256);
-                    else
-                        hipLaunchKernelGGL(encode_hc_nat_kernel<4>, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
-                                           (unsigned long long*)ws, (uint8_t*)ws + 256);
+                    }
                     HIP_TRY(hipGetLastError());
                 }
                 count_dispatch(LZ4HIP_K_HC_LANE);
@@ -304,13 +320,13 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             }
             if (ws) {
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                if (hc_gen == 2 && small)
-                    hipLaunchKernelGGL(encode_hc_conv_kernel<uint16_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                                       (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
-                else if (hc_gen == 2)
+                if (hc_gen == 2 && !small)
                     hipLaunchKernelGGL(encode_hc_conv_kernel<uint32_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                        (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
-#ifdef LZ4HIP_TUNING_BUILD                                              /* round-2 kernel, for A/B runs (tools/hc_gen_ab.py) */
+#ifdef LZ4HIP_TUNING_BUILD                                              /* the kernels generation 3 replaced, for A/B runs (tools/hc_gen_ab.py) */
+                else if (hc_gen == 2)
+                    hipLaunchKernelGGL(encode_hc_conv_kernel<uint16_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
+                                       (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);
                 else if (hc_gen == 1)
                     hipLaunchKernelGGL(encode_hc_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                        (unsigned long long*)ws, (uint8_t*)ws + 256, (unsigned long long)slab);

@@ -1,0 +1,291 @@
+// lz4hip_hc_lcp.hpp -- batched LZ4HC for blocks <= 64 KiB, one LANE per block, over precomputed chains that also carry the
+// number of bytes each position shares with its chain predecessor: a chain walk of the best-match search reads ONE table entry
+// per candidate and the input not at all.  Bit-exact to LZ4_compressHCCtx and its match finder (original/lz4hc.c:330-755).
+//
+// lz4hip_hc_nat.hpp removed the insert loop; what was left was the walk -- 110 k hops per fuzzer block, each one a chain entry
+// and a candidate probe in two different lines of memory, at the fabric's random-sector rate.  The reference's candidate test
+// (lz4hc.c:426-431: *(ref + ml) == *(ip + ml), then A32(ref) == A32(ip), then the exact common length mlt, keep if mlt > ml) is
+// a pure function of F(c) = the exact common length of the search position ip and the candidate c: the candidate is kept iff
+// F(c) >= 4 and F(c) > ml.  And F along a chain follows from the table: with c' the chain predecessor of c and
+// lcp[c] = the common length of c and c',
+//      F(c') = min(F(c), lcp[c])   if F(c) != lcp[c],          F(c') >= F(c)   if they are equal (then compare on from there).
+// The table entry of position p is  chain[p] | lcp[p] << 16  (u32; lcp capped at 255 = "255 or more: compare on", and at
+// matchlimit - p, which no search from a later position can reach), built up front for every position by two kernels:
+// hc_nat_chain_kernel<uint32_t> (natural chains, lz4hip_hc_nat.hpp) and hc_lcp_fill_kernel (the block staged in LDS, one
+// position per thread).  The first candidate's length is lcp[ip] itself (the entry of the search position, read before ip is
+// inserted: its predecessor is the bucket's head), so the repeat detection (lz4hc.c:411-421) needs no input either.
+// The repeat fill (lz4hc.c:437-455) writes  delta | min(255, ip + repl - q) << 16  for q in [ip, end): the run's positions
+// share exactly the rest of the matched region with their predecessor at distance delta.
+// The wider-match search (lz4hc.c:462-518) walks the same way; its filter byte *(startLimit + longest) vs
+// *(ref - delta + longest) lies inside the known common region for almost every candidate (no load), the backward extension
+// reads the input as before.
+#pragma once
+#include "lz4hip_hc_nat.hpp"
+
+namespace lz4hip {
+
+constexpr size_t kHcLcpTableBytes = 65536 * sizeof(uint32_t);   // per block
+constexpr int kHcLcpFillThreads = 256;
+constexpr int kHcLcpFillLdsBytes = 65536 + 16;
+constexpr int kHcLcpCap = 255;
+
+// lcp[p] for every position p of block first + blockIdx.x whose chain entry hc_nat_chain_kernel<uint32_t> has written.
+__global__ void __launch_bounds__(kHcLcpFillThreads) hc_lcp_fill_kernel(Batch b, long long first, uint8_t* tables)
+{
+    LZ4HIP_DYN_LDS(lds);
+    const int tid = (int)threadIdx.x;
+    const int64_t blk = (int64_t)first + blockIdx.x;
+    const int n = batch_src_len(b, blk);
+    if (n > 65536) return;
+    const uint8_t* const in = batch_src(b, blk);
+    uint32_t* const table = (uint32_t*)(tables + (size_t)blockIdx.x * kHcLcpTableBytes);
+    for (int i = tid * 16; i < n; i += kHcLcpFillThreads * 16) {
+        if (i + 16 <= n) { const Vec16 v = load_v16(in + i); wv::store16(lds + i, v.w[0], v.w[1], v.w[2], v.w[3]); }
+        else for (int k = i; k < n; k++) lds[k] = in[k];
+    }
+    wv::block_sync();
+    const uint32_t* const lw = (const uint32_t*)lds;
+    auto word_at = [&](int x) -> uint32_t { return wv::alignbyte(lw[(x >> 2) + 1], lw[x >> 2], (uint32_t)x & 3u); };
+    const int matchlimit = n - kLastLiterals;
+    // eight positions per thread and round; the entries of the next round are loaded (addresses clamped, no branches) while
+    // this round's lengths are counted in LDS
+    constexpr int U = 8;
+    const int lastp = n - 4;
+    if (lastp < 1) return;
+    auto entry_of = [&](int p) -> uint32_t { return table[p <= lastp ? p : lastp]; };
+    uint32_t e[U], e2[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) e[u] = entry_of(1 + tid + u * kHcLcpFillThreads);
+    for (int p0 = 1 + tid; p0 <= lastp; p0 += U * kHcLcpFillThreads) {
+#pragma unroll
+        for (int u = 0; u < U; u++) e2[u] = entry_of(p0 + (U + u) * kHcLcpFillThreads);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + u * kHcLcpFillThreads;
+            if (p > lastp) continue;
+            const int prev = p - (int)(e[u] & 0xFFFFu);
+            int cap = matchlimit - p;
+            cap = cap > kHcLcpCap ? kHcLcpCap : cap;
+            int off = 0;
+            while (off < cap) {
+                const uint32_t x = word_at(p + off) ^ word_at(prev + off);
+                if (x) { off += __builtin_ctz(x) >> 3; break; }
+                off += 4;
+            }
+            if (off > cap) off = cap;
+            if (off < 0) off = 0;
+            table[p] = (e[u] & 0xFFFFu) | ((uint32_t)off << 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = e2[u];
+    }
+}
+
+enum HcLcpState {
+    kLsFetch = 0,   // take the next block from the counter
+    kLsHead,        // the entry of the search position: its bucket's head and the length shared with it
+    kLsHop,         // one candidate: evaluate it, read its entry, derive the next candidate's length
+    kLsCmp,         // exact length where the table only gives a lower bound, 16 bytes per step
+    kLsBack,        // wider match only: backward extension, up to 4 bytes per step
+    kLsRepl,        // best match only: repeat optimisation fill, up to four entries per step
+    kLsCtrl,        // search complete: control flow up to the next search (or the end of the block)
+    kLsExit
+};
+
+// ctrl_every / ctrl_lanes: the control flow runs for all waiting lanes every ctrl_every-th iteration (a power of two) or as soon as
+// ctrl_lanes lanes wait (lz4hip_hc_parse.inc).
+__global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long first, long long count, unsigned long long* counter, uint8_t* tables,
+                                                           int ctrl_every, int ctrl_lanes)
+{
+    // the names the shared control flow (lz4hip_hc_parse.inc) uses for its states and its batching
+    constexpr int kHsCtrl = kLsCtrl, kHsFetch = kLsFetch;
+    const int kHcCtrlEvery = ctrl_every, kHcCtrlBatchLanes = ctrl_lanes;
+    // ---- the block ----
+    const uint8_t* in = nullptr;
+    uint8_t* out = nullptr;
+    uint32_t* table = nullptr;
+    int64_t blk = 0;
+    int n = 0, cap = 0, mflimit = 0, matchlimit = 0;
+    // ---- the parse (variables of LZ4_compressHCCtx, lz4hc.c:553-742) ----
+    int ip = 0, anchor = 0, op = 0;
+    int ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0, start0 = 0, ref0 = 0;
+    int ml = 0, ml2 = 0, ml3 = 0, ml0 = 0;
+    int phase = 0;                 // which search the control flow is waiting for: 0 best (ip), 1 wider -> ml2, 2 wider -> ml3
+    // ---- the search in progress ----
+    int st = kLsFetch;
+    int s_ip = 0, s_limit = 0, s_back = 0;      // position searched, start limit (wider), ip - start_limit
+    int s_len = 0;                 // best length so far (ml / longest)
+    int s_match = 0, s_start = 0;  // where it was found (and, wider, where it starts)
+    int s_ref = 0;                 // the candidate
+    int s_f = 0;                   // F(s_ref): exact common length of in[s_ip..] and in[s_ref..], capped at matchlimit - s_ip
+    int s_first = 0;               // s_ref is the bucket's head (the repeat detection looks at it, lz4hc.c:411)
+    int s_link = 0, s_lcp = 0;     // entry of s_ref (kept across the backward extension)
+    int attempts = 0;
+    uint32_t s_probe = 0;
+    int s_probe_ok = 0;            // s_probe is in[start_limit + longest] for the current s_len (wider)
+    int s_repl = 0, s_delta = 0;
+    int c_n = 0, c_s = 0, c_r = 0, c_fwd_end = 0;
+    // The search position's side of the length counts comes from a 32-byte register window of the input (searches follow each
+    // other a few bytes apart and count on from 4 .. 20 bytes): bytes [w_pos, w_pos + 32) of the block, refilled by the count
+    // that misses it.
+    uint32_t iw0 = 0, iw1 = 0, iw2 = 0, iw3 = 0, iw4 = 0, iw5 = 0, iw6 = 0, iw7 = 0;
+    int w_pos = -64;
+    auto win16 = [&](int o) -> Vec16 {                               // bytes [o, o + 16) of the window, 0 <= o <= 16
+        const int q = o >> 2;
+        const uint32_t sh = (uint32_t)o & 3u;
+        auto pick = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) { return q < 2 ? (q == 0 ? x0 : x1) : (q == 2 ? x2 : (q == 3 ? x3 : x4)); };
+        const uint32_t a0 = pick(iw0, iw1, iw2, iw3, iw4), a1 = pick(iw1, iw2, iw3, iw4, iw5), a2 = pick(iw2, iw3, iw4, iw5, iw6),
+                       a3 = pick(iw3, iw4, iw5, iw6, iw7), a4 = pick(iw4, iw5, iw6, iw7, 0u);
+        return Vec16{ { wv::alignbyte(a1, a0, sh), wv::alignbyte(a2, a1, sh), wv::alignbyte(a3, a2, sh), wv::alignbyte(a4, a3, sh) } };
+    };
+
+    auto request = [&](int pos, int start_limit, int longest, int match0, int start0_) {
+        s_ip = pos; s_limit = start_limit; s_back = pos - start_limit; s_len = longest; s_match = match0; s_start = start0_;
+        attempts = kHcAttempts; s_repl = 0; s_delta = 0; s_probe_ok = 0;
+        st = kLsHead;
+    };
+
+    int it = 0;
+    for (;;) {
+        if (st == kLsFetch) {
+            const long long k = (long long)atomicAdd(counter, 1ull);
+            if (k >= count) st = kLsExit;
+            else {
+                blk = (int64_t)first + k;
+                table = (uint32_t*)(tables + (size_t)k * kHcLcpTableBytes);
+                n = batch_src_len(b, blk); cap = batch_dst_cap(b, blk);
+                in = batch_src(b, blk); out = batch_dst(b, blk);
+                if (n > 65536) { b.result[blk] = -2000000002; st = kLsFetch; }   // LZ4HIP_E_ARGUMENT: this launch is for blocks <= 64 KiB
+                else {
+                    mflimit = n - kMfLimit; matchlimit = n - kLastLiterals;
+                    ip = 1; anchor = 0; op = 0;                                  // lz4hc.c:581
+                    phase = 3; st = kLsCtrl; w_pos = -64;
+                }
+            }
+        }
+        if (!wv::any(st != kLsExit)) break;
+
+#include "lz4hip_hc_parse.inc"
+
+        // ================= one memory step of the state each lane is in =================
+        const bool inH = st == kLsHead, inP = st == kLsHop, inC = st == kLsCmp, inB = st == kLsBack, inL = st == kLsRepl;
+        const int f_a = s_ip + c_n, f_b = s_ref + c_n;
+        const bool cmp16 = inC & (f_a + 16 <= matchlimit);
+        const bool back4 = inB & (c_s - s_limit >= 4) & (c_r >= 4);
+        // wider match: the filter byte *(startLimit + longest) vs *(ref - delta + longest) (lz4hc.c:478) is index j of the
+        // pair (ip, ref): inside the common region it is equal, at its end (a real mismatch) different, elsewhere it is read
+        const int fj = s_len - s_back;
+        const bool wide = inP & (phase != 0) & (s_f >= kMinMatch);
+        const bool f_pass = (fj >= 0) & (fj < s_f), f_fail = (fj == s_f) & (s_f < matchlimit - s_ip);
+        const bool f_read = wide & !f_pass & !f_fail;
+        // (1) table entry: of the search position / of the candidate
+        uint32_t v_e = 0;
+        if (inH | inP) v_e = table[inH ? s_ip : s_ref];
+        // (2, 3) wider match: the candidate's filter byte; the search position's when the best length has changed
+        uint32_t v_cb = 0, v_pb = 0;
+        if (f_read) v_cb = in[s_ref - s_back + s_len];
+        if (f_read & (s_probe_ok == 0)) v_pb = in[s_limit + s_len];
+        // (4, 5) backward extension: 4 bytes before both starts
+        uint32_t v_w = 0, v_w2 = 0;
+        if (back4) { v_w = load_u32(in + c_s - 4); v_w2 = load_u32(in + c_r - 4); }
+        // (6, 7) exact length: 16 bytes of both sides
+        Vec16 v_x = { { 0, 0, 0, 0 } }, v_y = { { 0, 0, 0, 0 } }, v_x2 = { { 0, 0, 0, 0 } };
+        const bool w_hit = (f_a >= w_pos) & (f_a + 16 <= w_pos + 32);
+        const bool w_fill = cmp16 & !w_hit & (f_a + 32 <= n);        // (the miss also fetches the following 16 bytes: the new window)
+        if (cmp16) v_y = load_v16(in + f_b);
+        if (cmp16 & !w_hit) v_x = load_v16(in + f_a);
+        if (w_fill) v_x2 = load_v16(in + f_a + 16);
+
+        // ---- process ----
+        // the next candidate of the walk: c' = c - chain[c], F(c') from F(c) and lcp[c]; ends the search when the walk is over
+        auto advance = [&]() {
+            const int c2 = s_ref - s_link;
+            if (!(c2 >= s_ip - kMaxDistance && attempts > 0 && c2 >= 0)) { st = (s_repl && phase == 0) ? (int)kLsRepl : (int)kLsCtrl; return; }
+            const int l = s_lcp;
+            s_ref = c2; s_first = 0;
+            if (s_f < l) { st = kLsHop; }                                        // F(c') = F(c)
+            else if (s_f > l && l < kHcLcpCap) { s_f = l; st = kLsHop; }         // F(c') = lcp[c]
+            else { c_n = l; st = kLsCmp; }                          // equal, or both >= 255: at least l, compare on
+        };
+        if (inH) {                                                   // HASH_POINTER(ip) after LZ4HC_Insert(ip) == ip - natural chain[ip]
+            s_ref = s_ip - (int)(v_e & 0xFFFFu);
+            s_f = (int)(v_e >> 16);
+            s_first = 1;
+            if (s_f >= kHcLcpCap) { c_n = kHcLcpCap; st = kLsCmp; }
+            else st = kLsHop;                                        // (blocks <= 64 KiB: the head is always within MAX_DISTANCE)
+        } else if (inP) {
+            s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)(v_e >> 16);
+            if (phase == 0) {
+                if (s_first && s_ref >= s_ip - 4) {                  // lz4hc.c:411-421: not one of the attempts
+                    if (s_f >= kMinMatch) { s_delta = (s_ip - s_ref) & 0xFFFF; s_repl = s_len = s_f; s_match = s_ref; }
+                } else {                                             // lz4hc.c:424-434
+                    attempts--;
+                    if (s_f >= kMinMatch && s_f > s_len) { s_len = s_f; s_match = s_ref; }
+                }
+                advance();
+            } else {                                                 // lz4hc.c:474-516
+                attempts--;
+                bool pass = false;
+                if (wide) {
+                    if (f_read) {
+                        if (!s_probe_ok) { s_probe = v_pb; s_probe_ok = 1; }
+                        pass = v_cb == s_probe;
+                    } else pass = f_pass;
+                }
+                if (pass) { c_fwd_end = s_ip + s_f; c_s = s_ip; c_r = s_ref; st = kLsBack; }
+                else advance();
+            }
+        } else if (inC) {                                            // common length of in[s_ip + c_n ..] and in[s_ref + c_n ..] up to matchlimit
+            int add = 0;
+            bool more = false;
+            if (cmp16) {
+                if (w_hit) v_x = win16(f_a - w_pos);
+                else if (w_fill) {
+                    iw0 = v_x.w[0]; iw1 = v_x.w[1]; iw2 = v_x.w[2]; iw3 = v_x.w[3]; iw4 = v_x2.w[0]; iw5 = v_x2.w[1]; iw6 = v_x2.w[2]; iw7 = v_x2.w[3];
+                    w_pos = f_a;
+                }
+                const uint64_t d0 = (v_x.w[0] ^ v_y.w[0]) | ((uint64_t)(v_x.w[1] ^ v_y.w[1]) << 32);
+                const uint64_t d1 = (v_x.w[2] ^ v_y.w[2]) | ((uint64_t)(v_x.w[3] ^ v_y.w[3]) << 32);
+                if (d0) add = __builtin_ctzll(d0) >> 3;
+                else if (d1) add = 8 + (__builtin_ctzll(d1) >> 3);
+                else { add = 16; more = true; }
+            } else {                                                 // the last bytes before matchlimit, one by one (rare)
+                while (f_a + add < matchlimit && in[f_a + add] == in[f_b + add]) add++;
+            }
+            c_n += add;
+            if (!more) { s_f = c_n; st = kLsHop; }
+        } else if (inB) {
+            bool more = false;
+            if (back4) {
+                const uint32_t d = v_w ^ v_w2;                       // bytes c_s-4 .. c_s-1 against c_r-4 .. c_r-1: count from the top
+                const int k = d == 0 ? 4 : (__builtin_clz(d) >> 3);
+                c_s -= k; c_r -= k; more = k == 4;
+            } else {
+                for (int k = 0; k < 4; k++) {
+                    if (c_s > s_limit && c_r > 0 && in[c_s - 1] == in[c_r - 1]) { c_s--; c_r--; more = k == 3; }
+                    else { more = false; break; }
+                }
+            }
+            if (!more) {                                             // lz4hc.c:507-512
+                if (c_fwd_end - c_s > s_len) { s_len = c_fwd_end - c_s; s_match = c_r; s_start = c_s; s_probe_ok = 0; }
+                advance();
+            }
+        } else if (inL) {                                            // lz4hc.c:437-455: DELTANEXT(q) = delta for q in [ip, end)
+            if (s_repl > 0) { c_s = s_ip; c_r = s_ip + s_repl - 3; c_fwd_end = s_ip + s_repl; s_repl = -1; }
+            int q = c_s;
+            const uint32_t d = (uint32_t)s_delta;
+            auto entry = [&](int at) -> uint32_t { const int l = c_fwd_end - at; return d | ((uint32_t)(l > kHcLcpCap ? kHcLcpCap : l) << 16); };
+            if ((q & 3) == 0 && q + 4 <= c_r) {
+                store_v16((uint8_t*)(table + q), Vec16{ { entry(q), entry(q + 1), entry(q + 2), entry(q + 3) } });
+                q += 4;
+            } else {
+                table[q] = entry(q);
+                q++;
+            }
+            c_s = q;
+            if (q >= c_r) { s_repl = 0; st = kLsCtrl; }
+        }
+    }
+}
+
+}  // namespace lz4hip

@@ -32,14 +32,13 @@
 namespace lz4hip {
 
 constexpr size_t kHcNatChainBytes = 65536 * sizeof(uint16_t);   // per block
-constexpr int kHcNatLdsBytes = 32768 * sizeof(uint16_t);        // heads of the chain builder
+constexpr int kHcNatTrashHead = 32768;                          // (a head slot for the lanes past the end of the block)
+constexpr int kHcNatLdsBytes = (32768 + 8) * sizeof(uint16_t);  // heads of the chain builder
+constexpr int kHcNatAhead = 8;                                  // steps whose input words are in flight
 
 // The natural chain of blocks [first, first + gridDim.x): chains + k * kHcNatChainBytes is the table of block first + k.
-// One wavefront per block; per step the 64 lanes take 64 consecutive positions: read the bucket's head, write the own
-// position, read back.  A lane that does not find its own position has lost to another lane of the step with the same hash
-// (a few per cent of the steps on ordinary data, every step inside a run): those buckets are resolved exactly -- each of
-// their positions chains to the nearest lower lane of the bucket, the lowest to the head read before the step, the highest
-// becomes the head.
+// One wavefront per block; per step the 64 lanes take 64 consecutive positions, heads in LDS (64 KiB: two blocks per CU).
+template <class EntryT>          // uint16_t: the chain alone; uint32_t: room for lz4hip_hc_lcp.hpp's length byte (written as 0 here)
 __global__ void __launch_bounds__(64) hc_nat_chain_kernel(Batch b, long long first, uint8_t* chains)
 {
     LZ4HIP_DYN_LDS(lds);
@@ -49,45 +48,68 @@ __global__ void __launch_bounds__(64) hc_nat_chain_kernel(Batch b, long long fir
     const int n = wv::uniform(batch_src_len(b, blk));
     if (n > 65536) return;                                           // (the lane kernel reports it)
     const uint8_t* const in = batch_src(b, blk);
-    uint16_t* const chain = (uint16_t*)(chains + (size_t)blockIdx.x * kHcNatChainBytes);
+    EntryT* const chain = (EntryT*)(chains + (size_t)blockIdx.x * 65536 * sizeof(EntryT));
     for (int i = lane * 16; i < kHcNatLdsBytes; i += 64 * 16) wv::store16(lds + i, 0u, 0u, 0u, 0u);
     if (lane == 0) chain[0] = 0xFFFF;                                // never inserted: DELTANEXT(base) keeps its initial value (lz4hc.c:333)
     wv::mem_sync();
     const int last = n - 4;                                          // last position that has a 4-byte word
-    for (int base = 1; base <= last; base += 64) {
+    // one step: positions base .. base + 63, `word` = this lane's 4 bytes.  The lanes of the step that share a bucket are
+    // found with fifteen ballots, one per hash bit (`same` = the lanes whose hash equals mine): fuzzer-style data repeats words
+    // at distances below 64 in most steps, and resolving the groups one by one cost 1800 cycles per step.  Each position
+    // chains to the nearest lower lane of its bucket, the lowest to the head read before the step; the highest becomes the
+    // head.  Straight-line code (lanes past the end use a trash head slot and re-store entry 0), so that the compiler can count
+    // the loads in flight instead of waiting for all of them.
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    auto step = [&](int base, uint32_t word) {
         const int p = base + lane;
         const bool active = p <= last;
-        const uint32_t h = active ? hash15(load_u32(in + p)) : 0xFFFFFFFFu;
-        int prev = active ? (int)head[h] : 0;
-        wv::mem_sync();                                              // every head read before any head write
-        if (active) head[h] = (uint16_t)p;
-        wv::mem_sync();
-        const bool lost = active && head[h] != (uint16_t)p;
-        uint64_t todo = wv::ballot(lost);
-        if (todo) {
-            while (todo) {
-                const int k = __builtin_ctzll(todo);
-                const uint32_t hk = wv::readlane(h, k);
-                const uint64_t grp = wv::ballot(active && h == hk);
-                if (active && h == hk) {
-                    const uint64_t below = grp & ((1ull << lane) - 1ull);
-                    if (below) prev = base + (63 - __builtin_clzll(below));
-                    if (((grp >> lane) >> 1) == 0) head[h] = (uint16_t)p;
-                }
-                todo &= ~grp;
-            }
-            wv::mem_sync();
+        const uint32_t h = active ? hash15(word) : (uint32_t)kHcNatTrashHead;
+        const int old = (int)head[h];
+        asm volatile("" ::: "memory");                               // (issue the read here, ahead of the ballots; it is waited for where `old` is used)
+        uint64_t diff = ~wv::ballot(active);                         // lanes whose hash differs from mine in some bit
+#pragma unroll
+        for (int k = 0; k < 15; k++) {
+            const int32_t mine = (int32_t)(h << (31 - k)) >> 31;     // bit k of my hash: 0 or -1 (v_bfe_i32)
+            diff |= wv::ballot(mine != 0) ^ (uint64_t)(int64_t)mine;
         }
-        if (active) chain[p] = (uint16_t)(p - prev);
+        const uint64_t same = ~diff;
+        const uint64_t below = same & lanes_below;
+        const int prev = below ? base + (63 - __builtin_clzll(below)) : old;
+        const bool is_last = ((same >> lane) >> 1) == 0;
+        wv::mem_sync();                                              // every head read before any head write
+        head[(active & is_last) ? h : (uint32_t)kHcNatTrashHead] = (uint16_t)p;
+        wv::mem_sync();
+        chain[active ? p : 0] = active ? (EntryT)(p - prev) : (EntryT)0xFFFF;
+    };
+    // The steps depend on each other only through the heads in LDS; the input words do not, and a step that waited for its own
+    // 4-byte load paid a trip to memory per 64 positions (2400 cycles per step measured).  So the words of the next kHcNatAhead
+    // steps are loaded (addresses clamped to the block, no branches) while the current ones are processed.
+    constexpr int U = kHcNatAhead;
+    const int steps = last >= 1 ? (last + 63) / 64 : 0;
+    if (steps == 0) return;
+    auto word_of = [&](int s) -> uint32_t { const int p = 1 + s * 64 + lane; return load_u32(in + (p <= last ? p : last)); };
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = word_of(u);
+    for (int s0 = 0; s0 < steps; s0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) nxt[u] = word_of(s0 + U + u);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int base = 1 + (s0 + u) * 64;
+            if (base <= last) step(base, cur[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
 }
 
 // One lane = one block at a time (blocks [first, first + count), handed out by an atomic counter); all 64 lanes of the
 // wavefront iterate together until every lane has run out of blocks.  The state machine of lz4hip_hc_conv.hpp without
 // kHsZero / kHsInsert; chains + k * kHcNatChainBytes holds the natural chain of block first + k (hc_nat_chain_kernel).
-// WPS = wavefronts per SIMD the register budget is for (4: 100 VGPRs; 5: 96 and 16 bytes of scratch).
-template <int WPS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) encode_hc_nat_kernel(Batch b, long long first, long long count, unsigned long long* counter, uint8_t* chains)
+// (100 VGPRs: four wavefronts per SIMD; a budget for five -- 96 and 16 bytes of scratch -- is slower, and 8 wavefronts per CU
+//  are within 10 % of 16: the kernel sits at the fabric's random-sector rate, profiles/r03/hc_precomputed_chains.txt)
+__global__ void __launch_bounds__(64) encode_hc_nat_kernel(Batch b, long long first, long long count, unsigned long long* counter, uint8_t* chains)
 {
     // ---- the block ----
     const uint8_t* in = nullptr;

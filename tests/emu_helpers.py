@@ -74,7 +74,7 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     return res, dst
 
 
-def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=False):
+def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=False, lcp=False):
     src, sl = pack(blocks)
     if caps is None:
         caps = [len(b) + len(b) // 255 + 16 for b in blocks]
@@ -83,7 +83,9 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=Fa
     dst = np.full((len(blocks), ds), 0xA5, np.uint8)
     res = np.zeros(len(blocks), np.int32)
     args = (_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(blocks)))
-    if hc and nat:
+    if hc and lcp:
+        lib().emu_encode_hc_lcp(*args, groups)
+    elif hc and nat:
         lib().emu_encode_hc_nat(*args, groups)
     elif hc and conv:
         lib().emu_encode_hc_conv(*args, 1, int(max(len(b) for b in blocks) > 65536))

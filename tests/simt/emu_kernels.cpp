@@ -18,6 +18,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
 #include "lz4hip_hc_nat.hpp"
+#include "lz4hip_hc_lcp.hpp"
 #endif
 
 using namespace lz4hip;
@@ -203,8 +204,25 @@ void emu_encode_hc_nat(const uint8_t* src, int64_t src_stride, const int32_t* sr
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* chains = ws.data() + 256;
-    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel(b, 0, chains); });
-    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_nat_kernel<4>(b, 0, (long long)n, counter, chains); });
+    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint16_t>(b, 0, chains); });
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_nat_kernel(b, 0, (long long)n, counter, chains); });
+}
+#endif
+
+#ifdef LZ4HIP_HAVE_HC
+// LZ4HC over chains that carry shared lengths (lz4hip_hc_lcp.hpp): chain builder, length fill, lane kernel
+void emu_encode_hc_lcp(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                       int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static std::vector<uint8_t> ws;
+    ws.assign(256 + (size_t)n * kHcLcpTableBytes, 0x5A);      // poisoned
+    memset(ws.data(), 0, 256);
+    unsigned long long* counter = (unsigned long long*)ws.data();
+    uint8_t* tables = ws.data() + 256;
+    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint32_t>(b, 0, tables); });
+    simt::launch(dim3((unsigned)n), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, [=] { hc_lcp_fill_kernel(b, 0, tables); });
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_lcp_kernel(b, 0, (long long)n, counter, tables, kHcCtrlEvery, kHcCtrlBatchLanes); });
 }
 #endif
 

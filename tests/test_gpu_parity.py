@@ -563,14 +563,13 @@ def _nat_blocks(oracle, n, seed, big_every=40):
     return blocks
 
 
-@pytest.mark.parametrize("hc_gen", [3, 2], ids=["precomputed-chains", "convergent"])
-def test_hc_lane_small_blocks_many_per_lane(gpu, oracle, hc_gen):
-    """The LZ4HC lane kernels for blocks <= 64 KiB with ONE wavefront in the grid: 640 blocks, ten per lane.  Generation 3
-    (lz4hip_hc_nat.hpp, the default) builds the natural chains of the whole chunk first; generation 2 is the state machine
-    with the insert loop.  EVERY block is compared with the oracle."""
+def test_hc_lane_small_blocks_many_per_lane(gpu, oracle):
+    """The LZ4HC lane kernel for blocks <= 64 KiB (lz4hip_hc_nat.hpp: natural chains of the whole chunk built first, then the
+    state machine without an insert loop) with ONE wavefront in the grid: 640 blocks, ten per lane.  EVERY block is compared
+    with the oracle."""
     from lz4net_amd import _lib
     blocks = _nat_blocks(oracle, 640, 5)
-    with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1, hc_gen=hc_gen):
+    with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1):
         res, dst = gpu.encode(blocks, hc=True)
     for i, a in enumerate(blocks):
         w = oracle.compress(a, hc=True)

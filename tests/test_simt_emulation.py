@@ -210,36 +210,43 @@ def test_encode_hc_limited_output(oracle, lane):
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
-def test_encode_hc_nat_bit_exact(oracle):
-    """LZ4HC over precomputed natural chains (lz4hip_hc_nat.hpp: chain builder + lane kernel without the insert loop)."""
+PRECOMPUTED = pytest.mark.parametrize("kind", ["nat", "lcp"], ids=["natural-chains", "chains-with-shared-lengths"])
+
+
+@PRECOMPUTED
+def test_encode_hc_nat_bit_exact(oracle, kind):
+    """LZ4HC over precomputed tables: lz4hip_hc_nat.hpp (chain builder + lane kernel without the insert loop) and
+    lz4hip_hc_lcp.hpp (the chains also carry the length each position shares with its predecessor: walks read no input)."""
     blocks = _blocks(oracle, sizes=(0, 1, 4, 5, 12, 13, 14, 64, 65, 66, 300, 4096, 20000, 65536))
     blocks.append(oracle.gen(3, 3, 0, 1, 65536)[0])
     blocks.append(np.zeros(65536, np.uint8))
     blocks.append(np.tile(np.frombuffer(b"abc", np.uint8), 21846)[:65536].copy())
-    res, dst = emu.encode(blocks, hc=True, nat=True, groups=2)
+    res, dst = emu.encode(blocks, hc=True, groups=2, **{kind: True})
     for i, a in enumerate(blocks):
         want = oracle.compress(a, hc=True)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
         assert np.array_equal(dst[i, :res[i]], want), (i, a.size)
-    # a block > 64 KiB is refused by this kernel (the library launches lz4hip_hc_conv.hpp for such batches)
-    res, dst = emu.encode([oracle.gen(2, 3, 0, 2).reshape(-1)[:70000].copy(), blocks[10]], hc=True, nat=True, groups=1)
+    # a block > 64 KiB is refused by these kernels (the library launches lz4hip_hc_conv.hpp for such batches)
+    res, dst = emu.encode([oracle.gen(2, 3, 0, 2).reshape(-1)[:70000].copy(), blocks[10]], hc=True, groups=1, **{kind: True})
     assert res[0] == -2000000002 and res[1] == len(oracle.compress(blocks[10], hc=True))
 
 
-def test_encode_hc_nat_limited_output(oracle):
+@PRECOMPUTED
+def test_encode_hc_nat_limited_output(oracle, kind):
     blocks = _blocks(oracle, sizes=(13, 300, 4096))
     lens = [len(oracle.compress(a, hc=True)) for a in blocks]
     for delta in (0, -1, -7):
         caps = [max(l + delta, 0) for l in lens]
-        res, dst = emu.encode(blocks, caps=caps, hc=True, nat=True, groups=1)
+        res, dst = emu.encode(blocks, caps=caps, hc=True, groups=1, **{kind: True})
         for i, a in enumerate(blocks):
             want = oracle.compress_raw(a, caps[i], hc=True)[0]
             assert res[i] == want, (i, delta, res[i], want)
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
-def test_encode_hc_nat_repeats_and_collisions(oracle):
-    """What the exactness argument of lz4hip_hc_nat.hpp rests on: runs of period 1-5 (the repeat optimisation rewires their
+@PRECOMPUTED
+def test_encode_hc_nat_repeats_and_collisions(oracle, kind):
+    """What the exactness arguments of lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp rest on: runs of period 1-5 (the repeat optimisation rewires their
     chains and skips their head updates), tiny alphabets (same words everywhere), copies of earlier content, runs with single
     disturbed bytes -- ONE wavefront, five blocks per lane, every block the oracle's bytes."""
     rng = np.random.default_rng(23)
@@ -269,7 +276,7 @@ def test_encode_hc_nat_repeats_and_collisions(oracle):
             for _ in range(int(rng.integers(0, 40))):
                 row[int(rng.integers(0, sz))] = int(rng.integers(0, 256))
         blocks.append(row)
-    res, dst = emu.encode(blocks, hc=True, nat=True, groups=1)
+    res, dst = emu.encode(blocks, hc=True, groups=1, **{kind: True})
     for i, a in enumerate(blocks):
         want = oracle.compress(a, hc=True)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
