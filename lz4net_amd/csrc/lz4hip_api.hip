@@ -79,7 +79,7 @@ constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
-constexpr int kHcLaneGeneration = 3;           // blocks <= 64 KiB; larger ones: 2
+constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
 int fail(int code, const std::string& what)
 {
@@ -302,9 +302,9 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                         HIP_TRY(hipGetLastError());
                         hipLaunchKernelGGL(hc_lcp_fill_kernel, dim3((unsigned)cnt), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
                         HIP_TRY(hipGetLastError());
-                        int every = knob(kKnobHcCtrlEvery) > 0 ? knob(kKnobHcCtrlEvery) : kHcCtrlEvery;
+                        int every = knob(kKnobHcCtrlEvery) > 0 ? knob(kKnobHcCtrlEvery) : kHcLcpCtrlEvery;
                         while (every & (every - 1)) every &= every - 1;          // (a power of two)
-                        const int lanes = knob(kKnobHcCtrlLanes) > 0 ? knob(kKnobHcCtrlLanes) : kHcCtrlBatchLanes;
+                        const int lanes = knob(kKnobHcCtrlLanes) > 0 ? knob(kKnobHcCtrlLanes) : kHcLcpCtrlLanes;
                         hipLaunchKernelGGL(encode_hc_lcp_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
                                            (unsigned long long*)ws, (uint8_t*)ws + 256, every, lanes);
                     } else {

@@ -28,6 +28,7 @@ constexpr size_t kHcLcpTableBytes = 65536 * sizeof(uint32_t);   // per block
 constexpr int kHcLcpFillThreads = 256;
 constexpr int kHcLcpFillLdsBytes = 65536 + 16;
 constexpr int kHcLcpCap = 255;
+constexpr int kHcLcpCtrlEvery = 8, kHcLcpCtrlLanes = 32;        // control-flow batching (profiles/r03/hc_chains_with_shared_lengths.txt)
 
 // lcp[p] for every position p of block first + blockIdx.x whose chain entry hc_nat_chain_kernel<uint32_t> has written.
 __global__ void __launch_bounds__(kHcLcpFillThreads) hc_lcp_fill_kernel(Batch b, long long first, uint8_t* tables)
@@ -197,16 +198,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
         if (w_fill) v_x2 = load_v16(in + f_a + 16);
 
         // ---- process ----
-        // the next candidate of the walk: c' = c - chain[c], F(c') from F(c) and lcp[c]; ends the search when the walk is over
-        auto advance = [&]() {
-            const int c2 = s_ref - s_link;
-            if (!(c2 >= s_ip - kMaxDistance && attempts > 0 && c2 >= 0)) { st = (s_repl && phase == 0) ? (int)kLsRepl : (int)kLsCtrl; return; }
-            const int l = s_lcp;
-            s_ref = c2; s_first = 0;
-            if (s_f < l) { st = kLsHop; }                                        // F(c') = F(c)
-            else if (s_f > l && l < kHcLcpCap) { s_f = l; st = kLsHop; }         // F(c') = lcp[c]
-            else { c_n = l; st = kLsCmp; }                          // equal, or both >= 255: at least l, compare on
-        };
+        bool adv = false;                                            // the walk moves on to the next candidate (below, once)
         if (inH) {                                                   // HASH_POINTER(ip) after LZ4HC_Insert(ip) == ip - natural chain[ip]
             s_ref = s_ip - (int)(v_e & 0xFFFFu);
             s_f = (int)(v_e >> 16);
@@ -222,7 +214,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
                     attempts--;
                     if (s_f >= kMinMatch && s_f > s_len) { s_len = s_f; s_match = s_ref; }
                 }
-                advance();
+                adv = true;
             } else {                                                 // lz4hc.c:474-516
                 attempts--;
                 bool pass = false;
@@ -233,7 +225,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
                     } else pass = f_pass;
                 }
                 if (pass) { c_fwd_end = s_ip + s_f; c_s = s_ip; c_r = s_ref; st = kLsBack; }
-                else advance();
+                else adv = true;
             }
         } else if (inC) {                                            // common length of in[s_ip + c_n ..] and in[s_ref + c_n ..] up to matchlimit
             int add = 0;
@@ -268,7 +260,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             }
             if (!more) {                                             // lz4hc.c:507-512
                 if (c_fwd_end - c_s > s_len) { s_len = c_fwd_end - c_s; s_match = c_r; s_start = c_s; s_probe_ok = 0; }
-                advance();
+                adv = true;
             }
         } else if (inL) {                                            // lz4hc.c:437-455: DELTANEXT(q) = delta for q in [ip, end)
             if (s_repl > 0) { c_s = s_ip; c_r = s_ip + s_repl - 3; c_fwd_end = s_ip + s_repl; s_repl = -1; }
@@ -284,6 +276,33 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             }
             c_s = q;
             if (q >= c_r) { s_repl = 0; st = kLsCtrl; }
+        }
+        // the next candidate of the walk: c' = c - chain[c], F(c') from F(c) and lcp[c]; ends the search when the walk is over
+        if (adv) {
+            const int c2 = s_ref - s_link;
+            if (!(c2 >= s_ip - kMaxDistance && attempts > 0 && c2 >= 0)) st = (s_repl && phase == 0) ? (int)kLsRepl : (int)kLsCtrl;
+            else {
+                const int l = s_lcp;
+                s_ref = c2; s_first = 0;
+                if (s_f < l) st = kLsHop;                                        // F(c') = F(c)
+                else if (s_f > l && l < kHcLcpCap) { s_f = l; st = kLsHop; }     // F(c') = lcp[c]
+                else { c_n = l; st = kLsCmp; }                                   // equal, or both >= 255: at least l, compare on
+            }
+        }
+        // A best-match search that is complete needs no sequence encode to know the next search (lz4hc.c:586-597: no match ->
+        // the next position; a match -> the wider search at ip + ml - 2): start it now instead of waiting for the batched control
+        // flow (three searches in four are best-match searches; waiting lanes were a third of all lane-iterations).
+        if ((st == kLsCtrl) & (phase == 0)) {
+            ml = s_len; ref = s_match;
+            if (!ml) {
+                ip++;
+                if (ip < mflimit) request(ip, ip, 0, ref, 0);
+                else phase = 3;                                      // (the control flow finishes the block)
+            } else {
+                start0 = ip; ref0 = ref; ml0 = ml;
+                if (ip + ml < mflimit) { phase = 1; request(ip + ml - 2, ip + 1, ml, ref2, start2); }
+                else phase = 4;
+            }
         }
     }
 }

@@ -222,7 +222,7 @@ void emu_encode_hc_lcp(const uint8_t* src, int64_t src_stride, const int32_t* sr
     uint8_t* tables = ws.data() + 256;
     simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint32_t>(b, 0, tables); });
     simt::launch(dim3((unsigned)n), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, [=] { hc_lcp_fill_kernel(b, 0, tables); });
-    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_lcp_kernel(b, 0, (long long)n, counter, tables, kHcCtrlEvery, kHcCtrlBatchLanes); });
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_lcp_kernel(b, 0, (long long)n, counter, tables, kHcLcpCtrlEvery, kHcLcpCtrlLanes); });
 }
 #endif
 
