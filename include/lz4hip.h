@@ -123,9 +123,12 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *   "decoder_gen", "decoder_ring" [LZ4HIP_DECODER_GEN, LZ4HIP_DECODER_RING]  lane decoder generation (0 default, 2, 3) and, for
  *                                 generation 3, the bytes of output ring per lane (0 default; other sizes exist only in
  *                                 libraries built with -DLZ4HIP_TUNING_BUILD)
- *   "hc_gen"                     [LZ4HIP_HC_GEN]  LZ4HC lane mapping: 0 default, 1 one loop nest per lane (lz4hip_hc_lane.hpp,
- *                                 tuning builds only), 2 the convergent state machine (lz4hip_hc_conv.hpp), 3 the state machine over
- *                                 precomputed chains, no insert loop (lz4hip_hc_nat.hpp; blocks <= 64 KiB, else 2)
+ *   "hc_gen"                     [LZ4HIP_HC_GEN]  LZ4HC lane mapping: 0 default (4 for blocks <= 64 KiB, else 2); 4 the state machine over
+ *                                 precomputed chains that carry shared lengths (lz4hip_hc_lcp.hpp), 2 the state machine with the
+ *                                 insert loop (lz4hip_hc_conv.hpp: blocks > 64 KiB; smaller ones only in tuning builds); 1 and 3 (one
+ *                                 loop nest per lane; precomputed chains without lengths) exist only in -DLZ4HIP_TUNING_BUILD libraries
+ *   "hc_ctrl_every", "hc_ctrl_lanes" [LZ4HIP_HC_CTRL_EVERY, LZ4HIP_HC_CTRL_LANES]  generation 4: the parse's control flow runs for all
+ *                                 waiting lanes every N-th iteration (a power of two) or as soon as M lanes wait (0 = defaults 8 / 32)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

@@ -54,7 +54,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
     { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
     { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
-    { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default, 1 lz4hip_hc_lane.hpp (tuning builds), 2 lz4hip_hc_conv.hpp, 3 lz4hip_hc_nat.hpp (no insert loop; blocks <= 64 KiB)
+    { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default; 4 lz4hip_hc_lcp.hpp (blocks <= 64 KiB), 2 lz4hip_hc_conv.hpp (larger blocks; <= 64 KiB in tuning builds); 1 lz4hip_hc_lane.hpp and 3 lz4hip_hc_nat.hpp in tuning builds only
     { "hc_ctrl_every", "LZ4HIP_HC_CTRL_EVERY", false }, { "hc_ctrl_lanes", "LZ4HIP_HC_CTRL_LANES", false },   // lz4hip_hc_lcp.hpp: control-flow batching (0 default)
 };
 std::atomic<int> g_knob[kKnobCount];
@@ -291,8 +291,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 // lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp: per chunk, the table builders (one workgroup per block), then the lane kernel
                 if (hc_gen == 4) {
                     HIP_TRY(hipFuncSetAttribute((const void*)hc_lcp_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHcLcpFillLdsBytes));
-                    HIP_TRY(hipFuncSetAttribute((const void*)hc_nat_chain_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kHcNatLdsBytes));
-                } else HIP_TRY(hipFuncSetAttribute((const void*)hc_nat_chain_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kHcNatLdsBytes));
+                }
                 for (int64_t first = 0; first < d.n_blocks; first += chunk) {
                     const int64_t cnt = d.n_blocks - first < chunk ? d.n_blocks - first : chunk;
                     int64_t g = (cnt + 63) / 64 < groups ? (cnt + 63) / 64 : groups;
@@ -308,10 +307,14 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                         hipLaunchKernelGGL(encode_hc_lcp_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
                                            (unsigned long long*)ws, (uint8_t*)ws + 256, every, lanes);
                     } else {
+#ifdef LZ4HIP_TUNING_BUILD
                         hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
                         HIP_TRY(hipGetLastError());
                         hipLaunchKernelGGL(encode_hc_nat_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
                                            (unsigned long long*)ws, (uint8_t*)ws + 256);
+#else
+                        return fail(LZ4HIP_E_ARGUMENT, "hc_gen: this library has no LZ4HC lane kernel of that generation");
+#endif
                     }
                     HIP_TRY(hipGetLastError());
                 }

@@ -26,7 +26,7 @@ namespace lz4hip {
 
 constexpr size_t kHcLcpTableBytes = 65536 * sizeof(uint32_t);   // per block
 constexpr int kHcLcpFillThreads = 256;
-constexpr int kHcLcpFillLdsBytes = 65536 + 16;
+constexpr int kHcLcpFillLdsBytes = 65536 + 32;                  // the block (+ the 16-byte compares' overshoot)
 constexpr int kHcLcpCap = 255;
 constexpr int kHcLcpCtrlEvery = 8, kHcLcpCtrlLanes = 32;        // control-flow batching (profiles/r03/hc_chains_with_shared_lengths.txt)
 
@@ -40,45 +40,117 @@ __global__ void __launch_bounds__(kHcLcpFillThreads) hc_lcp_fill_kernel(Batch b,
     if (n > 65536) return;
     const uint8_t* const in = batch_src(b, blk);
     uint32_t* const table = (uint32_t*)(tables + (size_t)blockIdx.x * kHcLcpTableBytes);
-    for (int i = tid * 16; i < n; i += kHcLcpFillThreads * 16) {
-        if (i + 16 <= n) { const Vec16 v = load_v16(in + i); wv::store16(lds + i, v.w[0], v.w[1], v.w[2], v.w[3]); }
-        else for (int k = i; k < n; k++) lds[k] = in[k];
+    // the block into LDS: the sixteen 16-byte loads of a thread are in flight together (addresses clamped to the block)
+    {
+        Vec16 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const int i = (tid + k * kHcLcpFillThreads) * 16; v[k] = n >= 16 ? load_v16(in + (i + 16 <= n ? i : n - 16)) : Vec16{ { 0, 0, 0, 0 } }; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = (tid + k * kHcLcpFillThreads) * 16;
+            if (i + 16 <= n) wv::store16(lds + i, v[k].w[0], v[k].w[1], v[k].w[2], v[k].w[3]);
+            else for (int j = i; j < n; j++) lds[j] = in[j];
+        }
     }
     wv::block_sync();
     const uint32_t* const lw = (const uint32_t*)lds;
-    auto word_at = [&](int x) -> uint32_t { return wv::alignbyte(lw[(x >> 2) + 1], lw[x >> 2], (uint32_t)x & 3u); };
     const int matchlimit = n - kLastLiterals;
-    // eight positions per thread and round; the entries of the next round are loaded (addresses clamped, no branches) while
-    // this round's lengths are counted in LDS
+    // Eight rows of 256 consecutive positions per round; the entries of the next round are loaded (addresses clamped, no
+    // branches) while this round's lengths are counted in LDS.
+    //  * Inside a match consecutive positions have consecutive predecessors, and then their lengths are consecutive too: if
+    //    prev(p) == prev(p - 1) + 1, position p shares exactly one byte less with its predecessor than p - 1 does (as long as
+    //    that is at least one byte).  So only the first lane of such a run (a LEADER) counts bytes -- up to 255 + 63, so that a
+    //    whole wavefront of followers can be served from one count -- and the others take its result through a shuffle; a
+    //    follower past the end of its leader's common bytes counts for itself afterwards.
+    //  * The counts of a thread's rows run as ONE loop over its queue of rows (16 bytes per step): a wavefront then iterates
+    //    max-over-lanes of the SUM of their counts' steps, not the sum over the rows of the longest count among 64 lanes.
     constexpr int U = 8;
     const int lastp = n - 4;
     if (lastp < 1) return;
+    const int lane = tid & 63;
+    const uint64_t lanes_le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
     auto entry_of = [&](int p) -> uint32_t { return table[p <= lastp ? p : lastp]; };
-    uint32_t e[U], e2[U];
+    uint32_t e[U], e2[U], r[U];
+    auto pick = [&](const uint32_t (&v)[U], int u) -> uint32_t {
+        uint32_t x = v[U - 1];
+#pragma unroll
+        for (int k = U - 2; k >= 0; k--) x = u == k ? v[k] : x;
+        return x;
+    };
+    // common bytes of in[p..] and in[p - chain..] for the rows of `todo` (bit u = row u of this round), at most room / 255 + extra
+    auto count_rows = [&](uint32_t todo, int p0, int extra) {
+        int u = 0, p = 0, prev = 0, cap = 0, off = 0;
+        bool fresh = true;
+        while (todo) {
+            if (fresh) {
+                u = __builtin_ctz(todo);
+                p = p0 + u * kHcLcpFillThreads;
+                prev = p - (int)(pick(e, u) & 0xFFFFu);
+                cap = matchlimit - p;
+                cap = cap < 0 ? 0 : (cap > kHcLcpCap + extra ? kHcLcpCap + extra : cap);
+                off = 0; fresh = false;
+            }
+            bool done = off >= cap;
+            if (!done) {                                             // 16 bytes of both sides: five aligned dwords each
+                const int xa = p + off, xb = prev + off;
+                const uint32_t* const wa = lw + (xa >> 2);
+                const uint32_t* const wb = lw + (xb >> 2);
+                const uint32_t sa = (uint32_t)xa & 3u, sb = (uint32_t)xb & 3u;
+                const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], a3 = wa[3], a4 = wa[4];
+                const uint32_t b0 = wb[0], b1 = wb[1], b2 = wb[2], b3 = wb[3], b4 = wb[4];
+                const uint32_t d0 = wv::alignbyte(a1, a0, sa) ^ wv::alignbyte(b1, b0, sb), d1 = wv::alignbyte(a2, a1, sa) ^ wv::alignbyte(b2, b1, sb);
+                const uint32_t d2 = wv::alignbyte(a3, a2, sa) ^ wv::alignbyte(b3, b2, sb), d3 = wv::alignbyte(a4, a3, sa) ^ wv::alignbyte(b4, b3, sb);
+                if (d0 | d1) { off += d0 ? (__builtin_ctz(d0) >> 3) : 4 + (__builtin_ctz(d1) >> 3); done = true; }
+                else if (d2 | d3) { off += d2 ? 8 + (__builtin_ctz(d2) >> 3) : 12 + (__builtin_ctz(d3) >> 3); done = true; }
+                else { off += 16; done = off >= cap; }
+            }
+            if (done) {
+                off = off > cap ? cap : off;
+#pragma unroll
+                for (int k = 0; k < U; k++) r[k] = u == k ? (uint32_t)off : r[k];
+                todo &= todo - 1;
+                fresh = true;
+            }
+        }
+    };
 #pragma unroll
     for (int u = 0; u < U; u++) e[u] = entry_of(1 + tid + u * kHcLcpFillThreads);
-    for (int p0 = 1 + tid; p0 <= lastp; p0 += U * kHcLcpFillThreads) {
+    for (int p0 = 1 + tid; p0 - tid <= lastp; p0 += U * kHcLcpFillThreads) {       // (whole wavefronts: the shuffles need every lane)
+        uint32_t leader_rows = 0, follower_rows = 0, late_rows = 0;
 #pragma unroll
-        for (int u = 0; u < U; u++) e2[u] = entry_of(p0 + (U + u) * kHcLcpFillThreads);
+        for (int u = 0; u < U; u++) {
+            e2[u] = entry_of(p0 + (U + u) * kHcLcpFillThreads);
+            r[u] = 0;
+            const int p = p0 + u * kHcLcpFillThreads;
+            const int prev = p - (int)(e[u] & 0xFFFFu);
+            const int prev_left = (int)wv::shuffle((uint32_t)prev, lane - 1);
+            const bool valid = p <= lastp;
+            const bool follower = valid & (lane > 0) & (prev == prev_left + 1);
+            leader_rows |= (valid & !follower) ? 1u << u : 0u;
+            follower_rows |= follower ? 1u << u : 0u;
+        }
+        count_rows(leader_rows, p0, 63);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t leaders = wv::ballot(((follower_rows >> u) & 1u) == 0u);
+            const int a = 63 - __builtin_clzll(leaders & lanes_le);   // my leader (myself if I am one; lane 0 always is)
+            const int from_leader = (int)wv::shuffle(r[u], a) - (lane - a);
+            if ((follower_rows >> u) & 1u) {
+                if (from_leader >= 1) r[u] = (uint32_t)from_leader;
+                else late_rows |= 1u << u;
+            }
+        }
+        count_rows(late_rows, p0, 0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int p = p0 + u * kHcLcpFillThreads;
-            if (p > lastp) continue;
-            const int prev = p - (int)(e[u] & 0xFFFFu);
-            int cap = matchlimit - p;
-            cap = cap > kHcLcpCap ? kHcLcpCap : cap;
-            int off = 0;
-            while (off < cap) {
-                const uint32_t x = word_at(p + off) ^ word_at(prev + off);
-                if (x) { off += __builtin_ctz(x) >> 3; break; }
-                off += 4;
-            }
-            if (off > cap) off = cap;
-            if (off < 0) off = 0;
-            table[p] = (e[u] & 0xFFFFu) | ((uint32_t)off << 16);
+            int room = matchlimit - p;
+            room = room < 0 ? 0 : (room > kHcLcpCap ? kHcLcpCap : room);
+            const uint32_t len = r[u] > (uint32_t)room ? (uint32_t)room : r[u];
+            if (p <= lastp) table[p] = (e[u] & 0xFFFFu) | (len << 16);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) e[u] = e2[u];
+        for (int k = 0; k < U; k++) e[k] = e2[k];
     }
 }
 
@@ -181,7 +253,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
         const bool f_read = wide & !f_pass & !f_fail;
         // (1) table entry: of the search position / of the candidate
         uint32_t v_e = 0;
-        if (inH | inP) v_e = table[inH ? s_ip : s_ref];
+        if (inH | inP | inC) v_e = table[inH ? s_ip : s_ref];
         // (2, 3) wider match: the candidate's filter byte; the search position's when the best length has changed
         uint32_t v_cb = 0, v_pb = 0;
         if (f_read) v_cb = in[s_ref - s_back + s_len];
@@ -205,29 +277,11 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             s_first = 1;
             if (s_f >= kHcLcpCap) { c_n = kHcLcpCap; st = kLsCmp; }
             else st = kLsHop;                                        // (blocks <= 64 KiB: the head is always within MAX_DISTANCE)
-        } else if (inP) {
-            s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)(v_e >> 16);
-            if (phase == 0) {
-                if (s_first && s_ref >= s_ip - 4) {                  // lz4hc.c:411-421: not one of the attempts
-                    if (s_f >= kMinMatch) { s_delta = (s_ip - s_ref) & 0xFFFF; s_repl = s_len = s_f; s_match = s_ref; }
-                } else {                                             // lz4hc.c:424-434
-                    attempts--;
-                    if (s_f >= kMinMatch && s_f > s_len) { s_len = s_f; s_match = s_ref; }
-                }
-                adv = true;
-            } else {                                                 // lz4hc.c:474-516
-                attempts--;
-                bool pass = false;
-                if (wide) {
-                    if (f_read) {
-                        if (!s_probe_ok) { s_probe = v_pb; s_probe_ok = 1; }
-                        pass = v_cb == s_probe;
-                    } else pass = f_pass;
-                }
-                if (pass) { c_fwd_end = s_ip + s_f; c_s = s_ip; c_r = s_ref; st = kLsBack; }
-                else adv = true;
-            }
-        } else if (inC) {                                            // common length of in[s_ip + c_n ..] and in[s_ref + c_n ..] up to matchlimit
+        }
+        // kLsCmp and kLsHop: a length count that completes in this step goes straight on to the candidate's evaluation -- the
+        // candidate's entry was loaded with the bytes that were compared (a third of the hops used to take two iterations)
+        bool hop_now = inP;
+        if (inC) {                                                   // common length of in[s_ip + c_n ..] and in[s_ref + c_n ..] up to matchlimit
             int add = 0;
             bool more = false;
             if (cmp16) {
@@ -245,8 +299,38 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
                 while (f_a + add < matchlimit && in[f_a + add] == in[f_b + add]) add++;
             }
             c_n += add;
-            if (!more) { s_f = c_n; st = kLsHop; }
-        } else if (inB) {
+            if (!more) {
+                s_f = c_n;
+                // (wider match: unless the filter byte has to be read -- then the candidate takes its own kLsHop step)
+                const bool known = (s_f < kMinMatch) | ((fj >= 0) & (fj < s_f)) | ((fj == s_f) & (s_f < matchlimit - s_ip));
+                if ((phase == 0) | known) hop_now = true;
+                else st = kLsHop;
+            }
+        }
+        if (hop_now) {
+            s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)(v_e >> 16);
+            if (phase == 0) {
+                if (s_first && s_ref >= s_ip - 4) {                  // lz4hc.c:411-421: not one of the attempts
+                    if (s_f >= kMinMatch) { s_delta = (s_ip - s_ref) & 0xFFFF; s_repl = s_len = s_f; s_match = s_ref; }
+                } else {                                             // lz4hc.c:424-434
+                    attempts--;
+                    if (s_f >= kMinMatch && s_f > s_len) { s_len = s_f; s_match = s_ref; }
+                }
+                adv = true;
+            } else {                                                 // lz4hc.c:474-516
+                attempts--;
+                bool pass = false;
+                if (s_f >= kMinMatch) {
+                    if (f_read) {                                    // (kLsHop lanes only: the bytes were loaded above)
+                        if (!s_probe_ok) { s_probe = v_pb; s_probe_ok = 1; }
+                        pass = v_cb == s_probe;
+                    } else pass = (fj >= 0) & (fj < s_f);
+                }
+                if (pass) { c_fwd_end = s_ip + s_f; c_s = s_ip; c_r = s_ref; st = kLsBack; }
+                else adv = true;
+            }
+        }
+        if (inB) {
             bool more = false;
             if (back4) {
                 const uint32_t d = v_w ^ v_w2;                       // bytes c_s-4 .. c_s-1 against c_r-4 .. c_r-1: count from the top

@@ -28,12 +28,12 @@
 // Blocks > 64 KiB (32-bit heads, chain slots that wrap) stay with lz4hip_hc_conv.hpp.
 #pragma once
 #include "lz4hip_hc_conv.hpp"
+#include <type_traits>
 
 namespace lz4hip {
 
 constexpr size_t kHcNatChainBytes = 65536 * sizeof(uint16_t);   // per block
-constexpr int kHcNatTrashHead = 32768;                          // (a head slot for the lanes past the end of the block)
-constexpr int kHcNatLdsBytes = (32768 + 8) * sizeof(uint16_t);  // heads of the chain builder
+constexpr int kHcNatLdsBytes = 32768 * sizeof(uint16_t);        // heads of the chain builder: exactly 64 KiB (two workgroups per CU)
 constexpr int kHcNatAhead = 8;                                  // steps whose input words are in flight
 
 // The natural chain of blocks [first, first + gridDim.x): chains + k * kHcNatChainBytes is the table of block first + k.
@@ -57,29 +57,33 @@ __global__ void __launch_bounds__(64) hc_nat_chain_kernel(Batch b, long long fir
     // found with fifteen ballots, one per hash bit (`same` = the lanes whose hash equals mine): fuzzer-style data repeats words
     // at distances below 64 in most steps, and resolving the groups one by one cost 1800 cycles per step.  Each position
     // chains to the nearest lower lane of its bucket, the lowest to the head read before the step; the highest becomes the
-    // head.  Straight-line code (lanes past the end use a trash head slot and re-store entry 0), so that the compiler can count
-    // the loads in flight instead of waiting for all of them.
+    // head.  FULL steps (all but the last of a block) are straight-line code, so that the compiler can count the loads in
+    // flight instead of waiting for all of them.
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    auto step = [&](int base, uint32_t word) {
+    auto step = [&](int base, uint32_t word, auto full) {
+        constexpr bool FULL = decltype(full)::value;
         const int p = base + lane;
-        const bool active = p <= last;
-        const uint32_t h = active ? hash15(word) : (uint32_t)kHcNatTrashHead;
-        const int old = (int)head[h];
+        const bool active = FULL || p <= last;
+        const uint32_t h = active ? hash15(word) : 0x8000u + (uint32_t)lane;   // (lanes past the end: a bucket of their own, never written)
+        const int old = (int)head[h & 0x7FFFu];
         asm volatile("" ::: "memory");                               // (issue the read here, ahead of the ballots; it is waited for where `old` is used)
-        uint64_t diff = ~wv::ballot(active);                         // lanes whose hash differs from mine in some bit
+        uint64_t diff = 0;                                           // lanes whose hash differs from mine in some bit
 #pragma unroll
-        for (int k = 0; k < 15; k++) {
-            const int32_t mine = (int32_t)(h << (31 - k)) >> 31;     // bit k of my hash: 0 or -1 (v_bfe_i32)
-            diff |= wv::ballot(mine != 0) ^ (uint64_t)(int64_t)mine;
+        for (int k = 0; k < 16; k++) {
+            if (FULL && k == 15) break;                              // (bit 15 only tells the lanes past the end apart)
+            const uint32_t mine = (uint32_t)((int32_t)(h << (31 - k)) >> 31);   // bit k of my hash: 0 or ~0 (v_bfe_i32)
+            diff |= wv::ballot(mine != 0u) ^ (((uint64_t)mine << 32) | mine);
         }
         const uint64_t same = ~diff;
         const uint64_t below = same & lanes_below;
         const int prev = below ? base + (63 - __builtin_clzll(below)) : old;
         const bool is_last = ((same >> lane) >> 1) == 0;
         wv::mem_sync();                                              // every head read before any head write
-        head[(active & is_last) ? h : (uint32_t)kHcNatTrashHead] = (uint16_t)p;
+        if (FULL) { if (is_last) head[h] = (uint16_t)p; }
+        else if (active & is_last) head[h] = (uint16_t)p;
         wv::mem_sync();
-        chain[active ? p : 0] = active ? (EntryT)(p - prev) : (EntryT)0xFFFF;
+        if (FULL) chain[p] = (EntryT)(p - prev);
+        else if (active) chain[p] = (EntryT)(p - prev);
     };
     // The steps depend on each other only through the heads in LDS; the input words do not, and a step that waited for its own
     // 4-byte load paid a trip to memory per 64 positions (2400 cycles per step measured).  So the words of the next kHcNatAhead
@@ -97,13 +101,15 @@ __global__ void __launch_bounds__(64) hc_nat_chain_kernel(Batch b, long long fir
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int base = 1 + (s0 + u) * 64;
-            if (base <= last) step(base, cur[u]);
+            if (base + 63 <= last) step(base, cur[u], std::true_type());
+            else if (base <= last) step(base, cur[u], std::false_type());
         }
 #pragma unroll
         for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
 }
 
+#ifdef LZ4HIP_TUNING_BUILD          /* the lane kernel lz4hip_hc_lcp.hpp replaced: kept for A/B runs (tools/hc_gen_ab.py) and the emulator tests */
 // One lane = one block at a time (blocks [first, first + count), handed out by an atomic counter); all 64 lanes of the
 // wavefront iterate together until every lane has run out of blocks.  The state machine of lz4hip_hc_conv.hpp without
 // kHsZero / kHsInsert; chains + k * kHcNatChainBytes holds the natural chain of block first + k (hc_nat_chain_kernel).
@@ -284,5 +290,7 @@ __global__ void __launch_bounds__(64) encode_hc_nat_kernel(Batch b, long long fi
         }
     }
 }
+
+#endif  // LZ4HIP_TUNING_BUILD
 
 }  // namespace lz4hip

@@ -529,7 +529,7 @@ def test_hc_lane_slab_reuse(gpu, oracle):
 
 
 def _nat_blocks(oracle, n, seed, big_every=40):
-    """Blocks <= 64 KiB that stress the exactness argument of lz4hip_hc_nat.hpp: short-period runs, tiny alphabets, copies of
+    """Blocks <= 64 KiB that stress the exactness arguments of lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp: short-period runs, tiny alphabets, copies of
     earlier content, runs with single disturbed bytes, plus fuzzer-style and record-like rows."""
     rng = np.random.default_rng(seed)
     blocks = []
@@ -564,9 +564,9 @@ def _nat_blocks(oracle, n, seed, big_every=40):
 
 
 def test_hc_lane_small_blocks_many_per_lane(gpu, oracle):
-    """The LZ4HC lane kernel for blocks <= 64 KiB (lz4hip_hc_nat.hpp: natural chains of the whole chunk built first, then the
-    state machine without an insert loop) with ONE wavefront in the grid: 640 blocks, ten per lane.  EVERY block is compared
-    with the oracle."""
+    """The LZ4HC lane kernel for blocks <= 64 KiB (lz4hip_hc_lcp.hpp: chains and shared lengths of the whole chunk built first
+    by hc_nat_chain_kernel + hc_lcp_fill_kernel, then the state machine without an insert loop) with ONE wavefront in the
+    grid: 640 blocks, ten per lane.  EVERY block is compared with the oracle."""
     from lz4net_amd import _lib
     blocks = _nat_blocks(oracle, 640, 5)
     with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_groups=1):
@@ -578,8 +578,8 @@ def test_hc_lane_small_blocks_many_per_lane(gpu, oracle):
 
 
 def test_hc_precomputed_chains_several_chunks(gpu, oracle):
-    """lz4hip_hc_nat.hpp over a batch larger than its chunk (4096 chain tables with one wavefront in the grid): 9000 short blocks
-    in ONE device batch = three rounds of chain builder + lane kernel on the same tables."""
+    """lz4hip_hc_lcp.hpp over a batch larger than its chunk (4096 tables with one wavefront in the grid): 9000 short blocks in ONE
+    device batch = three rounds of table builders + lane kernel on the same tables."""
     from lz4net_amd import _lib
     blocks = _nat_blocks(oracle, 9000, 9, big_every=3000)
     blocks = [b[:2500] for b in blocks]
