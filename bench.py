@@ -527,7 +527,7 @@ def main():
         # BASELINE configs[2] / [3]: one launch over the batch, HIP events on the launch stream, same algorithmic bytes
         "roofline_encode": side_roofline(enc_roof, "encode_fast", "lz4hip::encode_fast_kernel (one wavefront per block, 64-probe search, hands dense blocks over) + "
                                          "lz4hip::encode_fast_lane_kernel (LZ4_compress64kCtx, one lane per block, the blocks handed over)", enc_check),
-        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::hc_nat_chain_kernel + lz4hip::encode_hc_nat_kernel (LZ4_compressHCCtx: natural chains built up front, then one lane per block, convergent state machine without the insert loop)", hc_check),
+        "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::hc_nat_chain_kernel + hc_lcp_fill_kernel + encode_hc_lcp_kernel (LZ4_compressHCCtx: chains and shared lengths of every position built up front, then one lane per block, convergent state machine without the insert loop)", hc_check),
         "cpu_baseline": cpu,
         "verified": all_ok,
         "csrc_sha": csrc_sha(),

@@ -256,8 +256,9 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // 16-bit heads (64 KiB of LDS, two workgroups per CU) when every block is known to be <= 64 KiB:
         // uniform length, or per-block lengths with src_len_all carrying an upper bound (0 = unknown).
         const bool small = b->src_len_all > 0 && b->src_len_all <= 65536;
-        // Large batches: one lane per block (lz4hip_hc_lane.hpp), state in a per-lane global slab; if the slab
-        // cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
+        // Large batches: one lane per block -- blocks <= 64 KiB over tables built up front for a chunk of the batch
+        // (lz4hip_hc_lcp.hpp: chain + shared length per position), larger blocks with the insert loop and a per-lane global slab
+        // (lz4hip_hc_conv.hpp); if the workspace cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
         // The "hc" knob (LZ4HIP_HC=wave|lane at load time, lz4hip_tuning_set) overrides.
         const int force = knob(kKnobHc);
         // (a lane needs 1.3 - 2.4 s for its block, growing with the number of lanes in flight; the wavefront mapping does
