@@ -79,6 +79,7 @@ constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
+constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
 int fail(int code, const std::string& what)
@@ -261,9 +262,10 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // (lz4hip_hc_conv.hpp); if the workspace cannot be allocated, or the batch is small, one wavefront per block (lz4hip_hc.hpp).
         // The "hc" knob (LZ4HIP_HC=wave|lane at load time, lz4hip_tuning_set) overrides.
         const int force = knob(kKnobHc);
-        // (a lane needs 1.3 - 2.4 s for its block, growing with the number of lanes in flight; the wavefront mapping does
-        //  ~11 k blocks per second: measured crossover at 16 k blocks, profiles/r01/hc_small_batches.txt)
-        bool lane_per_block = d.n_blocks >= 16384;
+        // (a lane-mapped wavefront needs ~0.35 s for its 64 blocks <= 64 KiB however small the batch, the wavefront mapping does
+        //  ~11 k blocks per second: measured crossover at 4096 blocks, profiles/r03/hc_small_batches.txt; blocks > 64 KiB take
+        //  the kernel with the insert loop, 1.3 - 2.4 s: 16 k blocks, profiles/r01/hc_small_batches.txt)
+        bool lane_per_block = d.n_blocks >= (small ? 4096 : 16384);
         if (force == 1) lane_per_block = false;
         if (force == 2) lane_per_block = true;
         Lease lease;
@@ -596,7 +598,9 @@ void for_rows(int64_t n, size_t bytes, F f)
 // being processed (PCIe is full duplex), kernels of neighbouring slices overlap, and the host gathers / scatters next to
 // all that.
 template <class Run>
-int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
+// slice_hint > 0: blocks per slice wanted by the caller (LZ4HC: its lane kernels need ~0.35 s however few blocks a launch has, so
+// a batch goes in slices of up to 16384 blocks instead of ~2048).
+int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, int64_t slice_hint = 0)
 {
     int rc = check_batch(hb);
     if (rc) return rc;
@@ -623,7 +627,8 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
     const int auto_slices = (int)(n / 2048 < 1 ? 1 : (n / 2048 > 6 ? 6 : n / 2048));
     const int want_slices = knob(kKnobHostSlices) > 0 ? knob(kKnobHostSlices) : auto_slices;
     int64_t per_slice = (n + want_slices - 1) / want_slices;
-    const int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
+    int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
+    if (slice_hint > 0 && knob(kKnobHostSlices) <= 0) { per_slice = slice_hint; hi = hi > slice_hint ? hi : slice_hint; }
     per_slice = per_slice < lo ? lo : per_slice;
     per_slice = per_slice > hi ? hi : per_slice;
     per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
@@ -740,7 +745,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run)
 // (The "logical_devices" knob makes N workers out of fewer devices, wrapping around: how the threaded path is tested on
 // a one-GPU box.)
 template <class Run>
-int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run)
+int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run, int64_t slice_hint = 0)
 {
     int rc = check_batch(hb);
     if (rc) return rc;
@@ -789,7 +794,7 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
         int prev_dev = 0;
         HIP_TRY(hipGetDevice(&prev_dev));
         HIP_TRY(hipSetDevice(devs[0]));
-        rc = run_host_batch(&shards[0].b, dst_len_is_result, run);
+        rc = run_host_batch(&shards[0].b, dst_len_is_result, run, slice_hint);
         (void)hipSetDevice(prev_dev);
         if (rc) return rc;
     } else {
@@ -802,11 +807,11 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
             Shard* sh = &shards[(size_t)k];
             const int phys = devs[(size_t)k];
             const unsigned share = (unsigned)nd;
-            post_rc = w->post([sh, phys, share, dst_len_is_result, run] {
+            post_rc = w->post([sh, phys, share, dst_len_is_result, run, slice_hint] {
                 if (sh->b.n_blocks == 0) return;
                 if (hipSetDevice(phys) != hipSuccess) { sh->rc = LZ4HIP_E_DEVICE; sh->err = "hipSetDevice failed"; return; }
                 g_row_thread_share = share;
-                sh->rc = run_host_batch(&sh->b, dst_len_is_result, run);
+                sh->rc = run_host_batch(&sh->b, dst_len_is_result, run, slice_hint);
                 if (sh->rc) sh->err = g_last_error;                  // thread-local: carry it back to the caller
             });
             if (post_rc) { w->busy.unlock(); break; }
@@ -956,7 +961,8 @@ int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, v
 
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode)
 {
-    return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); });
+    return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); },
+                          mode == LZ4HIP_MODE_HC ? kHcHostSliceBlocks : 0);
 }
 
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
@@ -968,7 +974,8 @@ int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
 int lz4hip_encode_batch_host_multi(const lz4hip_batch_t* b, int mode, uint64_t device_mask)
 {
     return run_host_batch_multi(b, true, device_mask,
-                                [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); });
+                                [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); },
+                                mode == LZ4HIP_MODE_HC ? kHcHostSliceBlocks : 0);
 }
 
 int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_size, uint64_t device_mask)

@@ -589,3 +589,20 @@ def test_hc_precomputed_chains_several_chunks(gpu, oracle):
         w = oracle.compress(a, hc=True)
         assert res[i] == len(w), (i, a.size, res[i], len(w))
         assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+
+
+def test_hc_host_batch_takes_the_lane_mapping_from_4096_blocks(gpu, oracle):
+    """Default dispatch, nothing forced: a host-pointer LZ4HC batch of 4200 blocks <= 64 KiB goes to the device in ONE slice
+    (LZ4HC slices are 16384 blocks) and is encoded by the lane mapping (table builders + lz4hip_hc_lcp.hpp); 4000 blocks by the
+    wavefront mapping.  Every block is compared with the oracle."""
+    from lz4net_amd import _lib
+    blocks = [b[:700] for b in _nat_blocks(oracle, 4200, 13, big_every=100000)]
+    want = [oracle.compress(a, hc=True) for a in blocks]
+    for n, lane_expected in ((4200, True), (4000, False)):
+        before = _lib.dispatch_counts()
+        res, dst = gpu.encode(blocks[:n], hc=True)
+        after = _lib.dispatch_counts()
+        assert (after[_lib.K_HC_LANE] > before[_lib.K_HC_LANE]) == lane_expected, (n, before, after)
+        assert (after[_lib.K_HC_WAVE] > before[_lib.K_HC_WAVE]) == (not lane_expected), (n, before, after)
+        for i in range(n):
+            assert res[i] == len(want[i]) and np.array_equal(dst[i, :res[i]], want[i]), (n, i)

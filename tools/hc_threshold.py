@@ -4,9 +4,10 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import torch
 from lz4net_amd import batch, _lib
 nmax = 1 << 16
-raw = batch.synth(2, 3, 0, nmax)
+dist = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+raw = batch.synth(dist, 3, 0, nmax)
 comp = torch.empty((nmax, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
-for n in (4096, 8192, 16384, 32768, 65536):
+for n in (512, 1024, 2048, 4096, 8192, 16384, 32768):
     row = []
     for name in ("wave", "lane"):
         _lib.tuning_set("hc", name)
