@@ -248,12 +248,12 @@ def test_encode_hc_nat_limited_output(oracle, kind):
 def test_encode_hc_nat_repeats_and_collisions(oracle, kind):
     """What the exactness arguments of lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp rest on: runs of period 1-5 (the repeat optimisation rewires their
     chains and skips their head updates), tiny alphabets (same words everywhere), copies of earlier content, runs with single
-    disturbed bytes -- ONE wavefront, three blocks per lane, every block the oracle's bytes."""
+    disturbed bytes -- ONE wavefront, two blocks per lane, every block the oracle's bytes."""
     rng = np.random.default_rng(23)
     blocks = []
-    for i in range(192):
+    for i in range(128):
         mode = i % 5
-        sz = int(rng.integers(13, 6000)) if i % 64 else 65536 - int(rng.integers(0, 3000))
+        sz = 65536 - int(rng.integers(0, 3000)) if i in (2, 68) else int(rng.integers(13, 3000))
         if mode == 0:
             row = rng.integers(0, int(rng.integers(2, 4)), sz).astype(np.uint8)
         elif mode == 1:
