@@ -300,7 +300,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                     int64_t g = (cnt + 63) / 64 < groups ? (cnt + 63) / 64 : groups;
                     HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
                     if (hc_gen == 4) {
-                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint32_t>, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint32_t>, dim3((unsigned)cnt), dim3(kHcNatChainThreads), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
                         HIP_TRY(hipGetLastError());
                         hipLaunchKernelGGL(hc_lcp_fill_kernel, dim3((unsigned)cnt), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
                         HIP_TRY(hipGetLastError());
@@ -311,7 +311,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                                            (unsigned long long*)ws, (uint8_t*)ws + 256, every, lanes);
                     } else {
 #ifdef LZ4HIP_TUNING_BUILD
-                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)cnt), dim3(64), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
+                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)cnt), dim3(kHcNatChainThreads), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
                         HIP_TRY(hipGetLastError());
                         hipLaunchKernelGGL(encode_hc_nat_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
                                            (unsigned long long*)ws, (uint8_t*)ws + 256);

@@ -28,7 +28,6 @@
 // Blocks > 64 KiB (32-bit heads, chain slots that wrap) stay with lz4hip_hc_conv.hpp.
 #pragma once
 #include "lz4hip_hc_conv.hpp"
-#include <type_traits>
 
 namespace lz4hip {
 
@@ -37,72 +36,66 @@ constexpr int kHcNatLdsBytes = 32768 * sizeof(uint16_t);        // heads of the 
 constexpr int kHcNatAhead = 8;                                  // steps whose input words are in flight
 
 // The natural chain of blocks [first, first + gridDim.x): chains + k * kHcNatChainBytes is the table of block first + k.
-// One wavefront per block; per step the 64 lanes take 64 consecutive positions, heads in LDS (64 KiB: two blocks per CU).
+// One workgroup of TWO wavefronts per block, heads in LDS (64 KiB: two blocks = four wavefronts per CU, one per SIMD).  A step
+// is 64 consecutive positions; wavefront w takes the steps s = w, w + 2, ...  What a step costs is finding the lanes that
+// share a bucket (fifteen ballots, ~110 of its ~135 vector instructions) and that needs no heads, so the two wavefronts do it
+// side by side; only the short head phases -- read the bucket's old head, write the new one, store the chain entries --
+// alternate between them under two LDS-only barriers per pair of steps (one wavefront per block was bound by its own
+// instruction issue: 152 ms per 2^18 blocks).
+constexpr int kHcNatChainThreads = 128;
 template <class EntryT>          // uint16_t: the chain alone; uint32_t: room for lz4hip_hc_lcp.hpp's length byte (written as 0 here)
-__global__ void __launch_bounds__(64) hc_nat_chain_kernel(Batch b, long long first, uint8_t* chains)
+__global__ void __launch_bounds__(kHcNatChainThreads) hc_nat_chain_kernel(Batch b, long long first, uint8_t* chains)
 {
     LZ4HIP_DYN_LDS(lds);
     uint16_t* const head = (uint16_t*)lds;
     const int lane = wv::lane();
+    const int w = wv::wave_in_block();
     const int64_t blk = (int64_t)first + blockIdx.x;
     const int n = wv::uniform(batch_src_len(b, blk));
     if (n > 65536) return;                                           // (the lane kernel reports it)
     const uint8_t* const in = batch_src(b, blk);
     EntryT* const chain = (EntryT*)(chains + (size_t)blockIdx.x * 65536 * sizeof(EntryT));
-    for (int i = lane * 16; i < kHcNatLdsBytes; i += 64 * 16) wv::store16(lds + i, 0u, 0u, 0u, 0u);
-    if (lane == 0) chain[0] = 0xFFFF;                                // never inserted: DELTANEXT(base) keeps its initial value (lz4hc.c:333)
-    wv::mem_sync();
+    for (int i = (int)threadIdx.x * 16; i < kHcNatLdsBytes; i += kHcNatChainThreads * 16) wv::store16(lds + i, 0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) chain[0] = 0xFFFF;                         // never inserted: DELTANEXT(base) keeps its initial value (lz4hc.c:333)
     const int last = n - 4;                                          // last position that has a 4-byte word
-    // one step: positions base .. base + 63, `word` = this lane's 4 bytes.  The lanes of the step that share a bucket are
-    // found with fifteen ballots, one per hash bit (`same` = the lanes whose hash equals mine): fuzzer-style data repeats words
-    // at distances below 64 in most steps, and resolving the groups one by one cost 1800 cycles per step.  Each position
-    // chains to the nearest lower lane of its bucket, the lowest to the head read before the step; the highest becomes the
-    // head.  FULL steps (all but the last of a block) are straight-line code, so that the compiler can count the loads in
-    // flight instead of waiting for all of them.
+    const int steps = last >= 1 ? (last + 63) / 64 : 0;              // step s: positions 1 + 64 s + lane
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    auto step = [&](int base, uint32_t word, auto full) {
-        constexpr bool FULL = decltype(full)::value;
-        const int p = base + lane;
-        const bool active = FULL || p <= last;
-        const uint32_t h = active ? hash15(word) : 0x8000u + (uint32_t)lane;   // (lanes past the end: a bucket of their own, never written)
-        const int old = (int)head[h & 0x7FFFu];
-        asm volatile("" ::: "memory");                               // (issue the read here, ahead of the ballots; it is waited for where `old` is used)
-        uint64_t diff = 0;                                           // lanes whose hash differs from mine in some bit
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (FULL && k == 15) break;                              // (bit 15 only tells the lanes past the end apart)
-            const uint32_t mine = (uint32_t)((int32_t)(h << (31 - k)) >> 31);   // bit k of my hash: 0 or ~0 (v_bfe_i32)
-            diff |= wv::ballot(mine != 0u) ^ (((uint64_t)mine << 32) | mine);
-        }
-        const uint64_t same = ~diff;
-        const uint64_t below = same & lanes_below;
-        const int prev = below ? base + (63 - __builtin_clzll(below)) : old;
-        const bool is_last = ((same >> lane) >> 1) == 0;
-        wv::mem_sync();                                              // every head read before any head write
-        if (FULL) { if (is_last) head[h] = (uint16_t)p; }
-        else if (active & is_last) head[h] = (uint16_t)p;
-        wv::mem_sync();
-        if (FULL) chain[p] = (EntryT)(p - prev);
-        else if (active) chain[p] = (EntryT)(p - prev);
-    };
-    // The steps depend on each other only through the heads in LDS; the input words do not, and a step that waited for its own
-    // 4-byte load paid a trip to memory per 64 positions (2400 cycles per step measured).  So the words of the next kHcNatAhead
-    // steps are loaded (addresses clamped to the block, no branches) while the current ones are processed.
+    // The input words of a wavefront's next kHcNatAhead steps are in flight while the current ones are processed (addresses
+    // clamped to the block, no branches: the compiler can count them instead of waiting for all of them).
     constexpr int U = kHcNatAhead;
-    const int steps = last >= 1 ? (last + 63) / 64 : 0;
-    if (steps == 0) return;
-    auto word_of = [&](int s) -> uint32_t { const int p = 1 + s * 64 + lane; return load_u32(in + (p <= last ? p : last)); };
+    auto word_of = [&](int s) -> uint32_t { const int p = 1 + s * 64 + lane; return load_u32(in + (p <= last ? p : (last >= 0 ? last : 0))); };
     uint32_t cur[U], nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = word_of(u);
-    for (int s0 = 0; s0 < steps; s0 += U) {
+    for (int u = 0; u < U; u++) cur[u] = n >= 4 ? word_of(w + 2 * u) : 0u;
+    for (int j0 = 0; 2 * j0 < steps; j0 += U) {                      // (pair j: steps 2 j and 2 j + 1; both wavefronts run every pair)
 #pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = word_of(s0 + U + u);
+        for (int u = 0; u < U; u++) nxt[u] = word_of(w + 2 * (j0 + U + u));
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int base = 1 + (s0 + u) * 64;
-            if (base + 63 <= last) step(base, cur[u], std::true_type());
-            else if (base <= last) step(base, cur[u], std::false_type());
+            if (2 * (j0 + u) >= steps) break;                        // (uniform over the workgroup)
+            const int s = 2 * (j0 + u) + w;
+            const int base = 1 + s * 64, p = base + lane;
+            const bool active = p <= last;
+            // ---- the lanes of my step that share my bucket (no heads needed) ----
+            const uint32_t h = active ? hash15(cur[u]) : 0x8000u + (uint32_t)lane;   // (lanes past the end: a bucket of their own, never written)
+            uint64_t diff = 0;                                       // lanes whose hash differs from mine in some bit
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t mine = (uint32_t)((int32_t)(h << (31 - k)) >> 31);   // bit k of my hash: 0 or ~0 (v_bfe_i32)
+                diff |= wv::ballot(mine != 0u) ^ (((uint64_t)mine << 32) | mine);
+            }
+            const uint64_t same = ~diff;
+            const uint64_t below = same & lanes_below;
+            const bool is_last = ((same >> lane) >> 1) == 0;
+            // ---- the head phases, in step order: each position chains to the nearest lower lane of its bucket, the lowest to
+            //      the head read before the step; the highest becomes the head ----
+            wv::lds_barrier();                                       // the previous pair's second head phase is complete
+            int old = 0;
+            if (w == 0) { old = (int)head[h & 0x7FFFu]; asm volatile("" ::: "memory"); if (active & is_last) head[h] = (uint16_t)p; }
+            wv::lds_barrier();
+            if (w == 1) { old = (int)head[h & 0x7FFFu]; asm volatile("" ::: "memory"); if (active & is_last) head[h] = (uint16_t)p; }
+            const int prev = below ? base + (63 - __builtin_clzll(below)) : old;
+            if (active) chain[p] = (EntryT)(p - prev);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) cur[u] = nxt[u];

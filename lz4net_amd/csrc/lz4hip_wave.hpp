@@ -62,6 +62,9 @@ LZ4HIP_DEVICE void mem_sync()
 }
 
 LZ4HIP_DEVICE void block_sync() { __syncthreads(); }
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every global access the wavefront has in
+// flight (vmcnt(0)), which a kernel that keeps loads and stores in flight across its barriers must not pay.
+LZ4HIP_DEVICE void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // s_waitcnt vmcnt(0): every vector-memory access this wave has issued has finished.  Used right after a RARE load whose
 // destination registers are read in a hot loop: the compiler otherwise has to assume at the loop header that the load may

@@ -204,7 +204,7 @@ void emu_encode_hc_nat(const uint8_t* src, int64_t src_stride, const int32_t* sr
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* chains = ws.data() + 256;
-    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint16_t>(b, 0, chains); });
+    simt::launch(dim3((unsigned)n), dim3(kHcNatChainThreads), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint16_t>(b, 0, chains); });
     simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_nat_kernel(b, 0, (long long)n, counter, chains); });
 }
 #endif
@@ -220,7 +220,7 @@ void emu_encode_hc_lcp(const uint8_t* src, int64_t src_stride, const int32_t* sr
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
     uint8_t* tables = ws.data() + 256;
-    simt::launch(dim3((unsigned)n), dim3(64), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint32_t>(b, 0, tables); });
+    simt::launch(dim3((unsigned)n), dim3(kHcNatChainThreads), kHcNatLdsBytes, [=] { hc_nat_chain_kernel<uint32_t>(b, 0, tables); });
     simt::launch(dim3((unsigned)n), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, [=] { hc_lcp_fill_kernel(b, 0, tables); });
     simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_hc_lcp_kernel(b, 0, (long long)n, counter, tables, kHcLcpCtrlEvery, kHcLcpCtrlLanes); });
 }

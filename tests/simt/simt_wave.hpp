@@ -79,6 +79,7 @@ inline int rank_below(uint64_t m) { return __builtin_popcountll(m & ((1ull << la
 
 inline void mem_sync() { simt::yield(simt::WAIT_WAVE, 140); }
 inline void block_sync() { simt::yield(simt::WAIT_BLOCK, 150); }
+inline void lds_barrier() { simt::yield(simt::WAIT_BLOCK, 150); }
 inline void wait_vector_memory() {}                                  // (s_waitcnt vmcnt(0): nothing to wait for on the CPU)
 
 inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
