@@ -36,13 +36,14 @@ constexpr int kHcNatLdsBytes = 32768 * sizeof(uint16_t);        // heads of the 
 constexpr int kHcNatAhead = 8;                                  // steps whose input words are in flight
 
 // The natural chain of blocks [first, first + gridDim.x): chains + k * kHcNatChainBytes is the table of block first + k.
-// One workgroup of TWO wavefronts per block, heads in LDS (64 KiB: two blocks = four wavefronts per CU, one per SIMD).  A step
-// is 64 consecutive positions; wavefront w takes the steps s = w, w + 2, ...  What a step costs is finding the lanes that
-// share a bucket (fifteen ballots, ~110 of its ~135 vector instructions) and that needs no heads, so the two wavefronts do it
-// side by side; only the short head phases -- read the bucket's old head, write the new one, store the chain entries --
-// alternate between them under two LDS-only barriers per pair of steps (one wavefront per block was bound by its own
-// instruction issue: 152 ms per 2^18 blocks).
-constexpr int kHcNatChainThreads = 128;
+// One workgroup of FOUR wavefronts per block, heads in LDS (64 KiB: two blocks = eight wavefronts per CU).  A step is 64
+// consecutive positions; wavefront w takes the steps s = w, w + 4, ...  What a step costs is finding the lanes that share a
+// bucket (sixteen ballots, ~120 of its ~140 vector instructions) and that needs no heads, so the wavefronts do it side by side;
+// only the short head phases -- read the bucket's old head, write the new one -- take turns under LDS-only barriers, one
+// per step (one wavefront per block was bound by its own instruction issue on one SIMD of four: 152 ms per 2^18 blocks; two
+// wavefronts: 132 ms).
+constexpr int kHcNatChainWaves = 4;
+constexpr int kHcNatChainThreads = 64 * kHcNatChainWaves;
 template <class EntryT>          // uint16_t: the chain alone; uint32_t: room for lz4hip_hc_lcp.hpp's length byte (written as 0 here)
 __global__ void __launch_bounds__(kHcNatChainThreads) hc_nat_chain_kernel(Batch b, long long first, uint8_t* chains)
 {
@@ -64,16 +65,17 @@ __global__ void __launch_bounds__(kHcNatChainThreads) hc_nat_chain_kernel(Batch 
     // clamped to the block, no branches: the compiler can count them instead of waiting for all of them).
     constexpr int U = kHcNatAhead;
     auto word_of = [&](int s) -> uint32_t { const int p = 1 + s * 64 + lane; return load_u32(in + (p <= last ? p : (last >= 0 ? last : 0))); };
+    constexpr int W = kHcNatChainWaves;
     uint32_t cur[U], nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = n >= 4 ? word_of(w + 2 * u) : 0u;
-    for (int j0 = 0; 2 * j0 < steps; j0 += U) {                      // (pair j: steps 2 j and 2 j + 1; both wavefronts run every pair)
+    for (int u = 0; u < U; u++) cur[u] = n >= 4 ? word_of(w + W * u) : 0u;
+    for (int j0 = 0; W * j0 < steps; j0 += U) {                      // (round j: steps W j .. W j + W - 1; every wavefront runs every round)
 #pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = word_of(w + 2 * (j0 + U + u));
+        for (int u = 0; u < U; u++) nxt[u] = word_of(w + W * (j0 + U + u));
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (2 * (j0 + u) >= steps) break;                        // (uniform over the workgroup)
-            const int s = 2 * (j0 + u) + w;
+            if (W * (j0 + u) >= steps) break;                        // (uniform over the workgroup)
+            const int s = W * (j0 + u) + w;
             const int base = 1 + s * 64, p = base + lane;
             const bool active = p <= last;
             // ---- the lanes of my step that share my bucket (no heads needed) ----
@@ -89,11 +91,12 @@ __global__ void __launch_bounds__(kHcNatChainThreads) hc_nat_chain_kernel(Batch 
             const bool is_last = ((same >> lane) >> 1) == 0;
             // ---- the head phases, in step order: each position chains to the nearest lower lane of its bucket, the lowest to
             //      the head read before the step; the highest becomes the head ----
-            wv::lds_barrier();                                       // the previous pair's second head phase is complete
             int old = 0;
-            if (w == 0) { old = (int)head[h & 0x7FFFu]; asm volatile("" ::: "memory"); if (active & is_last) head[h] = (uint16_t)p; }
-            wv::lds_barrier();
-            if (w == 1) { old = (int)head[h & 0x7FFFu]; asm volatile("" ::: "memory"); if (active & is_last) head[h] = (uint16_t)p; }
+#pragma unroll
+            for (int turn = 0; turn < W; turn++) {
+                wv::lds_barrier();                                   // the previous step's head phase is complete
+                if (w == turn) { old = (int)head[h & 0x7FFFu]; asm volatile("" ::: "memory"); if (active & is_last) head[h] = (uint16_t)p; }
+            }
             const int prev = below ? base + (63 - __builtin_clzll(below)) : old;
             if (active) chain[p] = (EntryT)(p - prev);
         }
