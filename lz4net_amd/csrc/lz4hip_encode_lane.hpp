@@ -19,7 +19,7 @@
 
 namespace lz4hip {
 
-constexpr int kLaneEncodeWavesPerCu = 16;
+constexpr int kLaneEncodeWavesPerCu = 24;     // 16: 44.8, 24: 49.5, 32: 48.2 GB/s on D2 (profiles/r03/encoder_and_hc_residency_ab.txt)
 constexpr int kLaneTableBytes = 32768;      // per lane: tagged u32[8192] (64k variant) or u32[4096] (generic variant)
 
 // The hash table of one block as this mapping keeps it.  What the algorithm sees is exactly the reference's table
