@@ -223,6 +223,7 @@ LZ4HIP_DEVICE int lane_encode_hc_block(const uint8_t* __restrict__ in, int n, ui
     return op;
 }
 
+#ifdef LZ4HIP_TUNING_BUILD          /* round 2's kernel: launched only by tuning builds (tools/hc_gen_ab.py) and the emulator tests */
 // Persistent grid; `slabs` holds slab_bytes per lane of the grid.
 __global__ void __launch_bounds__(64) encode_hc_lane_kernel(Batch b, unsigned long long* counter, uint8_t* slabs, unsigned long long slab_bytes)
 {
@@ -240,5 +241,6 @@ __global__ void __launch_bounds__(64) encode_hc_lane_kernel(Batch b, unsigned lo
         b.result[blk] = r;
     }
 }
+#endif  // LZ4HIP_TUNING_BUILD
 
 }  // namespace lz4hip
