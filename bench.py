@@ -43,24 +43,28 @@ def csrc_sha() -> str:
 
 def committed_traffic(kind: str, dist: int, blocks: int):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
-    from profiles/r03 (or r02)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel sources and
-    this workload; otherwise None (a stale number would be a lie)."""
-    for rnd in ("r03", "r02"):
+    from profiles/r04 (or an earlier round)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel
+    sources and this workload; otherwise None (a stale number would be a lie)."""
+    sha = csrc_sha()
+    for rnd in ("r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-        if os.path.exists(f) and json.load(open(f)).get("csrc_sha") == csrc_sha():
-            break
-    else:
-        return None, None
-    d = json.load(open(f))
-    e = d.get(kind)
-    if d.get("csrc_sha") != csrc_sha() or not e or e.get("dist") != dist or e.get("blocks") != blocks:
-        return None, None
-    return int(e["bytes_per_launch"]), f"profiles/{rnd}/pmc_traffic.json[{kind}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch; csrc {d['csrc_sha']})"
+        if not os.path.exists(f):
+            continue
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("csrc_sha") != sha:
+            continue
+        e = d.get(kind)
+        if not e or e.get("dist") != dist or e.get("blocks") != blocks:
+            return None, None
+        return int(e["bytes_per_launch"]), (f"profiles/{rnd}/pmc_traffic.json[{kind}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                            f"separate passes, per launch; csrc {d['csrc_sha']})")
+    return None, None
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE if a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks PER GPU")
@@ -242,6 +246,11 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
 
 def main():
     args = parse_args()
+    if args.gpus is None:
+        # launched as `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world size is the answer
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus > 1 and int(os.environ.get("RANK", "0")) == 0:
+            print(f"[bench] --gpus not given: adopting WORLD_SIZE={args.gpus} from the launcher", file=sys.stderr)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_as_ranks(args)
     import torch
@@ -310,13 +319,23 @@ def main():
     # which physical device each rank really ran on (PCI bus id): n_gpus counts ranks, distinct_devices says whether they shared
     props = torch.cuda.get_device_properties(torch.cuda.current_device())
     dev_ids = [(os.uname().nodename, str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or torch.cuda.current_device()))]
+    rank_ms = [(rank, round(elapsed / args.steps * 1e3, 3), round(sum(kernel_ms) / len(kernel_ms), 3))]   # (rank, wall ms/step, kernel ms/step)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         gathered = [None] * world
         dist.all_gather_object(gathered, dev_ids[0])
         dev_ids = gathered
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_ms[0])
+        rank_ms = gathered
     distinct_devices = len(set(dev_ids))
+    if rank == 0 and world > 1:
+        # self-diagnosing multi-GPU runs: which device every rank sat on and how long ITS steps took
+        for (rk, wall, kern), dev in zip(rank_ms, dev_ids):
+            print(f"[bench] rank {rk}: device {dev[1]} on {dev[0]}: {wall} ms/step wall, {kern} ms/step kernel", file=sys.stderr)
+        if distinct_devices < world:
+            print(f"[bench] WARNING: {world} ranks ran on {distinct_devices} distinct device(s): this is a code-path check, NOT a scaling measurement", file=sys.stderr)
     elapsed = float(tmax.item())
     all_ok = int(stats[2].item()) == world
 
@@ -374,8 +393,16 @@ def main():
                     alt[f"decode_{name}_GBps"] = round(w.raw_bytes / (t / 1e3) / 1e9, 2)
                     alt[f"decode_{name}_ok"] = w.verify()
                 _lib.tuning_set("decoder", "auto")
+            other_check = None
+            if d in (2, 3) and not args.no_cpu and args.verify_budget > 0 and args.encoder == "auto":
+                # the OTHER sequence-dense distribution: every block of it against the CPU reference as well
+                try:
+                    other_check = full_corpus_encoder_check(torch, batch, w.comp, w.clen, False, d, seed, 0, 1, args.verify_budget)
+                except Exception as e:
+                    other_check = {"error": repr(e)}
             extras[DIST_NAMES[d]] = {
                 **alt,
+                **({"encode_fast_bit_exact_vs_cpu_reference": other_check} if other_check is not None else {}),
                 "decode_GBps": round(w.raw_bytes / (min(ms) / 1e3) / 1e9, 2),
                 "decode_frac_of_hbm_peak": round(w.algorithmic_bytes / (min(ms) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                 "encode_fast_GBps": round(w.raw_bytes / (w.encode_ms / 1e3) / 1e9, 2),
@@ -415,7 +442,7 @@ def main():
             }
             del raw, comp, back
             if not args.hc_only:
-                # the other sequence-dense distribution, round trip only (the whole-corpus CPU comparison is done on args.dist)
+                # the other sequence-dense distribution: round trip AND every block against the CPU reference
                 other = 3 if args.dist == 2 else 2
                 torch.cuda.empty_cache()
                 raw = batch.synth(other, seed, 0, m)
@@ -424,7 +451,14 @@ def main():
                 ms_o = min(event_ms(lambda: holder.__setitem__("c", batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)), torch) for _ in range(2))
                 back = torch.empty_like(raw)
                 used = batch.decode(comp, holder["c"], back, batch.BLOCK)
+                hc_other_check = None
+                if not args.no_cpu and args.verify_budget > 0:
+                    try:
+                        hc_other_check = full_corpus_encoder_check(torch, batch, comp, holder["c"], True, other, seed, 0, 1, args.verify_budget)
+                    except Exception as e:
+                        hc_other_check = {"error": repr(e)}
                 extras["LZ4HC " + DIST_NAMES[other]] = {
+                    "bit_exact_vs_cpu_reference": hc_other_check,
                     "encode_hc_GBps": round(m * batch.BLOCK / (ms_o / 1e3) / 1e9, 3),
                     "ratio": round(float(holder["c"].double().sum().item()) / (m * batch.BLOCK), 4), "blocks": m,
                     "roundtrip_ok": bool((used == holder["c"]).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0,
@@ -530,6 +564,9 @@ def main():
             "blocks_per_gpu": n, "block_bytes": batch.BLOCK, "distribution": DIST_NAMES[args.dist],
             "sharding": f"round-robin by rank, {world} rank(s), no data-path collective",
             "ranks": world, "distinct_devices": distinct_devices,
+            "per_rank_ms_per_step": {"min": min(r[1] for r in rank_ms), "max": max(r[1] for r in rank_ms),
+                                     "kernel_min": min(r[2] for r in rank_ms), "kernel_max": max(r[2] for r in rank_ms)},
+            "valid_scaling_point": distinct_devices == world,
             "frac_of_aggregate_hbm_peak": round(float(stats[0].item()) / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
         },
         "roofline": {

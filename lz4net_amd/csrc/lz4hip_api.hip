@@ -8,6 +8,7 @@
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
 #include "lz4hip_decode_lane3.hpp"
+#include "lz4hip_decode_lane4.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
@@ -79,6 +80,7 @@ constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
 constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
+constexpr int kLane4Config = 1192;           // generation 4: 192-byte ring, 64-byte input pieces, 128-byte flush units
 constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
@@ -390,6 +392,32 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
         } else
 #endif
+        if (gen == 4) {
+            // generation 4 (lz4hip_decode_lane4.hpp): input window in registers.  decoder_ring = ring bytes + 1000 x variant
+            // (variant 0: 64-byte pieces, 64-byte flush units; 1: 64 / 128; 2: 32 / 64; 3: 32 / 128)
+            const int cfg = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane4Config;
+#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH)                                                                                 \
+            do {                                                                                                                \
+                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+            } while (0)
+            switch (cfg) {
+            case kLane4Config: LZ4HIP_LAUNCH_LANE4(kLane4Config % 1000, (kLane4Config / 1000 & 2) ? 32 : 64, (kLane4Config / 1000 & 1) ? 128 : 64); break;
+#ifdef LZ4HIP_TUNING_BUILD
+            case 128: LZ4HIP_LAUNCH_LANE4(128, 64, 64); break;
+            case 2128: LZ4HIP_LAUNCH_LANE4(128, 32, 64); break;
+            case 192: LZ4HIP_LAUNCH_LANE4(192, 64, 64); break;
+            case 2192: LZ4HIP_LAUNCH_LANE4(192, 32, 64); break;
+            case 3192: LZ4HIP_LAUNCH_LANE4(192, 32, 128); break;
+            case 256: LZ4HIP_LAUNCH_LANE4(256, 64, 64); break;
+            case 1256: LZ4HIP_LAUNCH_LANE4(256, 64, 128); break;
+            case 3256: LZ4HIP_LAUNCH_LANE4(256, 32, 128); break;
+            case 1240: LZ4HIP_LAUNCH_LANE4(240, 64, 128); break;
+#endif
+            default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
+            }
+#undef LZ4HIP_LAUNCH_LANE4
+        } else
         if (gen != 3) return fail(LZ4HIP_E_ARGUMENT, "decoder_gen: this library has no lane decoder of that generation");
         else {
             const int ring = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane3RingBytes;

@@ -1,0 +1,457 @@
+// lz4hip_decode_lane4.hpp -- lane-per-block LZ4 decoder, fourth generation.
+//
+// Round 4 measured what bounds the third generation (lz4hip_decode_lane3.hpp) with a MEMORY SKELETON of it
+// (tools/decode_skeleton.hip: the kernel's global accesses for fuzzer-style / record-style data, no parsing):
+// the skeleton runs at 830 GB/s (D2) / 696 GB/s (D3) -- the real kernel's 829 / 698.  Generation 3 sits on the ceiling the
+// memory system sets for ITS ACCESS PATTERN, whatever its arithmetic costs; the same skeleton says what moves the ceiling
+// (profiles/r04/decode_skeleton_*.txt):
+//     input fetched as whole 64-byte sectors, once (not as two 32-byte halves 14 us apart)        +15 %
+//     192 bytes of output ring per lane instead of 128 (a quarter of the far-match fetches gone)   +15 %
+//     finished output leaving in 128-byte units (both sectors of a line in one store instruction)  +4 % (ring 192) .. +13 % (256)
+// All three need LDS that generation 3 spends on its 64-byte-per-lane input staging ring.  So here the INPUT WINDOW LIVES IN
+// REGISTERS (the kernel runs at three wavefronts per SIMD = 168 VGPRs, generation 3 used 104):
+//   * W[4 + P/4]: the last 16 bytes of the previous piece and one whole piece (P = 64: a sector) of the compressed
+//     stream, L[P/4]: the next piece, loaded by the lane itself with P/16 always-issued, predicated 16-byte loads as soon as
+//     the previous L has moved into W.  No staging ring, no load records, no helper lanes, no landing pass.
+//   * the 16 bytes at the input cursor (byte offset d into W) come out of W through a binary tree of v_cndmask_b32
+//     (log2(P/4) levels; measured: 4.5 SIMD-cycles per select, tools/microbench_select_tree.hip) and one byte rotation;
+//     the offset field of a sequence is picked out of those 16 bytes the same way.
+//   * LDS per wavefront = 64 x R + 512 bytes: R = 192 at the twelve wavefronts per CU generation 3 had with R = 128.
+// Everything else is generation 3's design: dword-interleaved output ring, appends by DS_MSKOR_B32 + v_perm_b32, cooperative
+// flush (four lanes per 64-byte line, or eight per 128-byte unit), far matches fetched from the lane's own output one and a
+// half iterations ahead, parse-ahead of one sequence, a byte-wise parser behind one wave-level branch, hand-counted vmcnt.
+//
+// Same functions / return conventions as lz4hip_decode.hpp (LZ4_uncompress, original/lz4.c:812-914;
+// LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
+#pragma once
+#include "lz4hip_common.hpp"
+
+#ifndef LZ4HIP_ITERATION_HOOK
+#define LZ4HIP_ITERATION_HOOK(lane) ((void)0)
+#endif
+
+namespace lz4hip {
+
+#ifndef LZ4HIP_DEC4_FLUSH_RECS
+#define LZ4HIP_DEC4_FLUSH_RECS 0      /* 0 = all the two store instructions can carry; the emulator's 'starved' build: 4 */
+#endif
+constexpr unsigned lane4_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + 16u * 32u; }
+
+enum L4Kind { kK4None = 0, kK4Near = 1, kK4Far = 2, kK4Lit = 3, kK4Zero = 4 };
+enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: final literal run / corrupt stream / no match yet (its header follows the literals)
+
+// All 64 lanes of the wavefront call this together and stay in the loop until the last one is done.
+//   R      bytes of output ring per lane (multiple of 16)
+//   P      bytes of input per piece (32 or 64), loaded by the lane itself
+//   FU     flush unit: 64 (one line, four lanes) or 128 (two adjacent lines, eight lanes)
+//   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
+template <bool KNOWN, int R, int P, int FU, int POL = 0>
+LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
+                                     uint8_t* dst, int oend)
+{
+    static_assert(R >= 128 && R % 16 == 0 && R <= 1008, "ring: a multiple of 16 bytes, 128 .. 1008");
+    static_assert(P == 32 || P == 64, "input piece: 32 or 64 bytes");
+    static_assert(FU == 64 || (FU == 128 && R >= 192), "flush unit: 64 bytes, or 128 with a ring of at least 192");
+    constexpr int RW = R / 4;                                        // ring rows (one dword per lane per row)
+    constexpr bool RPOW2 = (RW & (RW - 1)) == 0;
+    constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
+    constexpr int NW = 4 + P / 4, NL = P / 16;                       // window dwords, loads per piece
+    constexpr int HPR = FU / 16, RECS_PER_STORE = 64 / HPR;          // helper lanes per flush record, records per store instruction
+    constexpr int kFlushRecs = (LZ4HIP_DEC4_FLUSH_RECS) ? (LZ4HIP_DEC4_FLUSH_RECS) : 2 * RECS_PER_STORE;
+    constexpr int kNearMax = R - 20;                                 // an append writes whole dwords, up to 19 bytes past its last byte
+    constexpr int kVm = 3 + NL;                                      // vector-memory instructions per iteration: two flush stores, far fetch, NL input loads
+    Aligned16* const flush_rec = (Aligned16*)(lds + kRingBytes);
+    const uint32_t lane4 = (uint32_t)lane << 2;
+
+    // ring-relative byte address (row * 256 | lane * 4) plus k rows, wrapped
+    auto ring_add = [](uint32_t a, uint32_t rows256) -> uint32_t {
+        const uint32_t t = a + rows256;
+        if (RPOW2) return t & (kRingBytes - 1u);
+        const uint32_t u = t - kRingBytes;                           // (underflows unless t ran past the last row)
+        return u < t ? u : t;
+    };
+#define L4_RING(a) (*(uint32_t*)(lds + (a)))
+#define L4_PHASE_SEL(p_) wv::alignbyte(0x07060504u, 0x03020100u, (uint32_t)(p_) & 3u)
+
+    // ---- per-lane state ----
+    const int skew = (int)((uint64_t)src & (uint64_t)(P - 1));
+    const uint64_t src_al = (uint64_t)src - (uint64_t)skew;
+    const int in_total = iend > 0 ? (int)(((int64_t)skew + iend + P - 1) & ~(int64_t)(P - 1)) : 0;
+    int ip = 0;                  // input cursor (block coordinates): next token / next streamed literal / next header
+    // input window: W holds the bytes [wb, wb + 16 + P) of the aligned stream (wb = -16 mod P), L the piece that follows
+    uint32_t W[NW];
+    wv::u32x4 L[NL];
+    int wb = -16;
+    int lvalid = 0;              // L holds the piece at wb + 16 + P
+    int pend_a = 0, pend_b = 0;  // the loads of that piece are in flight (by the parity of the iteration that issued them)
+    int op = 0, fl = 0;          // bytes produced / bytes stored to dst (multiple of FU until the end of the block)
+    uint32_t oa = lane4;         // ring address of the dword that contains op
+    int kind = kK4None, rem = 0, off = 8;
+    int gready = 0;              // kK4Far: the 16 bytes fetched in the previous iteration are this lane's next chunk
+    // parsed-ahead sequence
+    int pv = 0, p_ll = 0, p_st = 0, p_ml = 0, p_off = 0, p_flags = 0, p_res = 0;
+    uint32_t p_l0 = 0, p_l1 = 0, p_l2 = 0;
+    int hdr = 0;                 // the cursor is at a sequence's offset field (its literals were streamed)
+    uint32_t token = 0;
+    int final_seen = 0, final_run = 0, result = 0, done = 0, flush_blocked = 0;
+    if (!active || (!KNOWN && iend == 0)) { done = 1; final_seen = 1; }   // lz4.c:946 returns -(0)
+    wv::u32x4 fa = { 0, 0, 0, 0 }, fb = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int j = 0; j < NW; j++) W[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) L[j] = wv::u32x4{ 0, 0, 0, 0 };
+    // the first two pieces (aligned pieces that overlap the source: they never leave the pages the source lies in)
+    if (done == 0) {
+        if (in_total > 0) {
+#pragma unroll
+            for (int j = 0; j < NL; j++) wv::load_global16(src_al + 16u * (unsigned)j, W[4 + 4 * j], W[5 + 4 * j], W[6 + 4 * j], W[7 + 4 * j]);
+        }
+        if (in_total > P) {
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                uint32_t a, b, c, e;
+                wv::load_global16(src_al + (uint64_t)P + 16u * (unsigned)j, a, b, c, e);
+                L[j] = wv::u32x4{ a, b, c, e };
+            }
+            lvalid = 1;
+        }
+    }
+    wv::wait_vector_memory();
+
+    // Append the low n_ bytes of the data dwords at op: rotated to the byte phase of op (one v_perm_b32 per dword), the
+    // first dword merged into the ring under a byte mask, the others stored whole.
+#define L4_APPEND(d0_, d1_, d2_, d3_, n_, FOUR_)                                                         \
+    do {                                                                                                \
+        const uint32_t sb_ = (uint32_t)op & 3u;                                                         \
+        const uint32_t s_ = wv::alignbyte(0x08070605u, 0x04030201u, sb_ ^ 3u);                          \
+        const uint32_t a1_ = ring_add(oa, 256u), a2_ = ring_add(oa, 512u), a3_ = ring_add(oa, 768u);    \
+        wv::lds_mskor(&L4_RING(oa), 0xFFFFFFFFu << (8u * sb_), wv::perm(d0_, 0u, s_));                  \
+        L4_RING(a1_) = wv::perm(d1_, d0_, s_);                                                          \
+        L4_RING(a2_) = wv::perm(d2_, d1_, s_);                                                          \
+        if (FOUR_) {                                                                                    \
+            L4_RING(a3_) = wv::perm(d3_, d2_, s_);                                                      \
+            L4_RING(ring_add(oa, 1024u)) = wv::perm(0u, d3_, s_);                                       \
+        } else {                                                                                        \
+            L4_RING(a3_) = wv::perm(0u, d2_, s_);                                                       \
+        }                                                                                               \
+        oa = ring_add(oa, ((sb_ + (uint32_t)(n_)) << 6) & 0x700u);                                      \
+        op += (n_);                                                                                     \
+    } while (0)
+
+    // One iteration.  ldF: the far-match registers loaded in THIS iteration; usF: those loaded in the previous one (consumed
+    // at the bottom of this one).  ld_pend / us_pend: this lane requested its next piece in this / the previous iteration.
+    auto iteration = [&](wv::u32x4& ldF, wv::u32x4& usF, int& ld_pend, int& us_pend) __attribute__((always_inline)) -> bool {
+        LZ4HIP_ITERATION_HOOK(lane);
+        // ================================ TOP ================================
+        // ---- (T1) the input window: take the next piece in once the cursor has left the current one; the 16 bytes at the
+        //      cursor; the 16 bytes at the source of the current near match ----
+        int d = ip + skew - wb;                                      // byte offset of the cursor in W: 0 .. 16 + P (+ 16 while a piece is awaited)
+        {
+            const bool no_more = wb + 16 + P >= in_total;            // W holds the last piece of the source
+            const bool cross = (d >= P) & ((lvalid != 0) | no_more);
+            const wv::mask_t cm = wv::cond(cross);
+#pragma unroll
+            for (int j = 0; j < 4; j++) W[j] = wv::sel(cm, W[P / 4 + j], W[j]);
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                W[4 + 4 * j] = wv::sel(cm, L[j].x, W[4 + 4 * j]); W[5 + 4 * j] = wv::sel(cm, L[j].y, W[5 + 4 * j]);
+                W[6 + 4 * j] = wv::sel(cm, L[j].z, W[6 + 4 * j]); W[7 + 4 * j] = wv::sel(cm, L[j].w, W[7 + 4 * j]);
+            }
+            wb += cross ? P : 0;
+            d -= cross ? P : 0;
+            lvalid = cross ? 0 : lvalid;
+        }
+        const bool staged16 = d < P;                                 // the 16 bytes at the cursor lie in W (what lies past the source is never used)
+        uint32_t x0, x1, x2, x3;
+        {
+            // W[k .. k + 4], k = d / 4, through a binary tree of selects; then the byte rotation
+            const uint32_t k = (uint32_t)d >> 2;
+            uint32_t t[NW];
+#pragma unroll
+            for (int j = 0; j < NW; j++) t[j] = W[j];
+            int n = NW;
+#pragma unroll
+            for (int sh = P / 8; sh >= 1; sh >>= 1) {
+                const wv::mask_t m = wv::cond((k & (uint32_t)sh) != 0u);
+                n -= sh;
+#pragma unroll
+                for (int j = 0; j < NW; j++)
+                    if (j < n) t[j] = wv::sel(m, t[j + sh], t[j]);
+            }
+            const uint32_t sx = L4_PHASE_SEL(d);
+            x0 = wv::perm(t[1], t[0], sx); x1 = wv::perm(t[2], t[1], sx); x2 = wv::perm(t[3], t[2], sx); x3 = wv::perm(t[4], t[3], sx);
+        }
+        uint32_t v0, v1, v2, v3;
+        {
+            // row of output byte op - off: (op >> 2) - ((off - (op & 3) + 3) >> 2) rows back from oa
+            const uint32_t offn = kind == kK4Near ? (uint32_t)off : 4u;        // (any other kind: some valid row)
+            const uint32_t back = ((offn + 3u - ((uint32_t)op & 3u)) << 6) & ~0xFFu;
+            uint32_t sa;
+            if (RPOW2) sa = (oa - back) & (kRingBytes - 1u);
+            else { const uint32_t t = oa - back, u = t + kRingBytes; sa = u < t ? u : t; }
+            const uint32_t r0 = L4_RING(sa), r1 = L4_RING(ring_add(sa, 256u)), r2 = L4_RING(ring_add(sa, 512u)),
+                           r3 = L4_RING(ring_add(sa, 768u)), r4 = L4_RING(ring_add(sa, 1024u));
+            const uint32_t sr = L4_PHASE_SEL((uint32_t)op - offn);
+            v0 = wv::perm(r1, r0, sr); v1 = wv::perm(r2, r1, sr); v2 = wv::perm(r3, r2, sr); v3 = wv::perm(r4, r3, sr);
+        }
+
+        // ---- (T2) flush finished output, FU bytes at a time, FU / 16 lanes per unit: ALWAYS two store instructions ----
+        {
+            const bool need = (done == 0) & (op - fl >= FU);
+            const uint64_t needy = wv::ballot(need);
+            const int cnt_all = wv::popc64(needy);
+            const bool go = cnt_all != 0;                            // wave-uniform
+            int cnt = 0;
+            bool mine = false;
+            if (go) {
+                cnt = cnt_all < kFlushRecs ? cnt_all : kFlushRecs;
+                const int frank = wv::rank_below(needy);
+                mine = need & (frank < kFlushRecs);
+                if (mine) {
+                    const uint64_t dp = (uint64_t)dst;
+                    // ring address of the unit: fl is a multiple of 4, so it starts floor((op - fl) / 4) rows before oa's row
+                    flush_rec[frank] = Aligned16{ { ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu)), (uint32_t)fl, (uint32_t)dp, (uint32_t)(dp >> 32) } };
+                }
+                wv::mem_sync();
+            }
+            const int sub = lane % HPR;
+#pragma unroll
+            for (int base = 0; base < 2 * RECS_PER_STORE; base += RECS_PER_STORE) {
+                const int idx = base + lane / HPR;
+                const bool act = idx < cnt;
+                uint64_t g = 0;
+                uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                if (act) {
+                    const Aligned16 r = flush_rec[idx];
+                    g = ((uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32)) + (uint64_t)(r.w[1] + 16u * (uint32_t)sub);
+                    // the owner's lane bits are in r.w[0]; this helper takes rows 4*sub .. 4*sub+3 of the unit
+                    const uint32_t b0 = ring_add(r.w[0], 1024u * (uint32_t)sub);
+                    q0 = L4_RING(b0); q1 = L4_RING(ring_add(b0, 256u)); q2 = L4_RING(ring_add(b0, 512u)); q3 = L4_RING(ring_add(b0, 768u));
+                }
+                wv::vm_store16_pred(act, g, q0, q1, q2, q3);
+            }
+            if (go) {
+                wv::mem_sync();                                      // records and ring rows are free to be overwritten again
+                fl += mine ? FU : 0;
+            }
+        }
+        // ---- (T3) size of this iteration's chunk of the current copy (appended at the bottom) ----
+        const bool room = op - fl <= R - 46;                         // this iteration's appends (<= 16 + 11 bytes + 19 of overshoot) stay clear of unflushed output
+        const bool near = kind == kK4Near, lit = kind == kK4Lit;
+        const bool can = room & (rem > 0) & !((kind == kK4Far) & (gready == 0)) & !(lit & !staged16);
+        const int stride = (near & (off < 16)) ? off : 16;          // a near match whose source would overlap the chunk copies `off` bytes and doubles off
+        int n = can ? (rem < stride ? rem : stride) : 0;
+        n = ((kind == kK4Zero) & (n > 8)) ? 8 : n;
+        const int rem_after = rem - n;
+        const int op_end = op + rem;                                 // where the current copy ends = where the parsed-ahead sequence's literals go
+
+        // ---- (T4) parse ahead: the next sequence's header (needs only the cursor) ----
+        const bool may_parse = (pv == 0) & (final_seen == 0) & !(lit & (rem > 0)) & staged16;
+        if (may_parse) {
+            const uint32_t tok = hdr ? token : (x0 & 255u);
+            const uint32_t t4 = tok >> 4, b1 = (x0 >> 8) & 255u, mlc = tok & 15u;
+            const bool e1 = (hdr == 0) & (t4 == 15u), e2 = mlc == 15u;
+            const int ll = hdr ? 0 : (int)t4 + (e1 ? (int)b1 : 0);
+            const bool in_win = (hdr != 0) | (t4 <= 11u);             // literals (<= 11, no length byte), offset and first match-length byte are within 16 bytes
+            const int o = hdr ? 0 : 1 + (int)t4;                      // position of the offset field when in_win (0 .. 12)
+            // offset + first match-length byte: bytes o .. o + 2 of the 16-byte view
+            uint32_t ot;
+            {
+                const uint32_t q = (uint32_t)o >> 2;
+                const wv::mask_t m1 = wv::cond((q & 1u) != 0u), m2 = wv::cond((q & 2u) != 0u);
+                const uint32_t lo = wv::sel(m2, wv::sel(m1, x3, x2), wv::sel(m1, x1, x0));
+                const uint32_t hi = wv::sel(m2, x3, wv::sel(m1, x2, x1));     // (q == 3: o == 12, byte phase 0, hi is not used)
+                ot = wv::alignbyte(hi, lo, (uint32_t)o & 3u);
+            }
+            const int vo = (int)(ot & 0xFFFFu);
+            const uint32_t extb = (ot >> 16) & 255u;
+            const int ml = (int)mlc + kMinMatch + (e2 ? (int)extb : 0);
+            const int lit_end = op_end + ll;
+            const int p_after = ip + o + 2;                          // after the offset field
+            // what the 16-byte view cannot decide goes to the byte-wise parser: the end of the source, length bytes of 255,
+            // the final literal run (lz4.c:851 / :965), every error (lz4.c:863,893 / :980,1024)
+            bool trap = (ip + 16 > iend) | (e1 & (b1 == 255u)) | (ip + 1 + (e1 ? 1 : 0) + ll > iend);
+            trap |= in_win & ((e2 & (extb == 255u)) | (vo > lit_end) | ((int64_t)lit_end + ml > (int64_t)oend - kLastLiterals));
+            if (KNOWN) trap |= (hdr == 0) & (lit_end > oend - 8);
+            else       trap |= ((hdr == 0) & ((lit_end > oend - kMfLimit) | (ip + 1 + (e1 ? 1 : 0) + ll > iend - 8))) | (in_win & e2 & !(p_after < iend - (kLastLiterals + 1)));
+            p_l0 = wv::alignbyte(x1, x0, 1); p_l1 = wv::alignbyte(x2, x1, 1); p_l2 = wv::alignbyte(x3, x2, 1);
+            token = tok;
+            p_ll = in_win ? ll : 0;
+            p_st = in_win ? 0 : ll;
+            p_ml = in_win ? ml : 0;
+            p_off = vo;
+            p_flags = in_win ? 0 : (int)kF4Header;
+            const int ip_fast = in_win ? p_after + (e2 ? 1 : 0) : ip + 1 + (e1 ? 1 : 0);
+            if (trap) {
+                // ---- byte-wise: token + literal length (lz4.c:844 / :957-961), or, in header position, offset + match length
+                //      (lz4.c:862-866 / :979-997); literals are always streamed from here, so the header gets its own parse ----
+                int err = 0, pos = ip;
+                if (!hdr) {
+                    const uint32_t tk = ip < iend ? src[ip] : 0u;
+                    int l = (int)(tk >> 4);
+                    pos = ip + 1;
+                    if (l == 15) {
+                        uint32_t b = 255;
+                        if (KNOWN) { do { b = pos < iend ? src[pos] : 0u; pos++; l += (int)b; if (l > (1 << 30)) { err = -pos; l = 0; break; } } while (b == 255); }
+                        else       { while (pos < iend && b == 255) { b = src[pos]; pos++; l += (int)b; l = l > (1 << 30) ? (1 << 30) : l; } }   // saturate: the reference counts in size_t
+                    }
+                    token = tk;
+                    const int le = (int)((int64_t)op_end + l > 0x7FFFFFFF ? 0x7FFFFFFF : op_end + l);
+                    const bool last = KNOWN ? (le > oend - 8) : ((le > oend - kMfLimit) | (pos + l > iend - 8));
+                    p_ll = 0; p_st = l; p_ml = 0; p_off = 8;
+                    if (last) {                                      // final literal run, lz4.c:851-858 / :965-975
+                        if (KNOWN) { if (err == 0 && (le != oend || pos + l > iend)) err = -pos; }
+                        else       { if (le > oend || pos + l != iend) err = -pos; }
+                        p_flags = kF4Final;
+                        p_res = KNOWN ? pos + l : le;
+                        final_seen = 1;
+                    } else {
+                        if (KNOWN && err == 0 && pos + l > iend) err = -pos;     // never read literals past the source
+                        p_flags = kF4Header;
+                    }
+                    ip = pos;
+                } else {
+                    int p = ip;
+                    const int o_ = (int)((p < iend ? src[p] : 0u) | ((p + 1 < iend ? src[p + 1] : 0u) << 8));
+                    p += 2;
+                    int m = (int)(token & 15u);
+                    if (m == 15) {
+                        if (KNOWN) {
+                            uint32_t b;
+                            while ((b = (p < iend ? src[p] : 0u)) == 255) { m += 255; p++; if (m > (1 << 30)) { err = -p; break; } }
+                            m += (int)b; p++;
+                        } else {
+                            while (p < iend - (kLastLiterals + 1)) { const uint32_t b = src[p]; p++; m += (int)b; m = m > (1 << 30) ? (1 << 30) : m; if (b != 255) break; }
+                        }
+                    }
+                    m += kMinMatch;
+                    if (err != 0) {}
+                    else if (op_end - o_ < 0) err = -(ip + 2);
+                    else if ((int64_t)op_end + m > (int64_t)oend - kLastLiterals) err = -p;
+                    p_ll = 0; p_st = 0; p_ml = m; p_off = o_; p_flags = 0;
+                    ip = p;
+                    hdr = 0;
+                }
+                if (err != 0) { p_flags = kF4Err; p_res = err; }
+                hdr = (p_flags & kF4Header) ? 1 : 0;
+            } else {
+                ip = ip_fast;
+                hdr = in_win ? 0 : 1;
+            }
+            pv = 1;
+        }
+
+        // ---- (T5) far fetch for the chunk appended at the bottom of the NEXT iteration: ALWAYS one load instruction ----
+        // continuation of the current far match, or the first 16 bytes of the parsed-ahead match if the current copy ends
+        // in this iteration (the source of the chunk appended at output position p is p - off; a lane that could not append
+        // what it holds simply fetches the same bytes again)
+        {
+            const bool f_cont = (kind == kK4Far) & (rem_after > 0);
+            const bool f_first = (rem_after == 0) & room & (pv != 0) & (p_ml != 0) & (p_flags == 0) & (p_off > kNearMax);
+            const int f_pos = f_cont ? op + n - off : op_end + p_ll - p_off;
+            const bool f_want = f_cont | f_first;
+            const bool f_do = f_want & (f_pos + 16 <= fl);
+            wv::vm_load16_pred<POL & 3>(f_do, (uint64_t)dst + (uint64_t)(uint32_t)f_pos, ldF);
+            flush_blocked = (f_want & !f_do) ? 1 : 0;
+            gready = f_do ? 1 : 0;                                   // (only read while kind == kK4Far)
+        }
+
+        // ---- (T6) the next piece of input, once L is free: ALWAYS NL load instructions, each lane for itself ----
+        {
+            const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for
+            const bool req = (done == 0) & (lvalid == 0) & (us_pend == 0) & (lpos < in_total);
+            const uint64_t g = src_al + (uint64_t)(uint32_t)lpos;
+#pragma unroll
+            for (int j = 0; j < NL; j++) wv::vm_load16_pred<(POL >> 2) & 3>(req, g + 16u * (unsigned)j, L[j]);
+            ld_pend = req ? 1 : 0;
+        }
+
+        // ================================ BOTTOM ================================
+        // ---- (B1) the loads of the PREVIOUS iteration have landed (this iteration's kVm accesses stay in flight) ----
+        wv::vm_wait_list<kVm>(usF, L);
+        lvalid = us_pend ? 1 : lvalid;
+        us_pend = 0;
+
+        // ---- (B3) append the chunk ----
+        {
+            const bool far_src = kind == kK4Far;
+            v0 = lit ? x0 : (far_src ? usF.x : v0);
+            v1 = lit ? x1 : (far_src ? usF.y : v1);
+            v2 = lit ? x2 : (far_src ? usF.z : v2);
+            v3 = lit ? x3 : (far_src ? usF.w : v3);
+            if ((kind == kK4Zero) & (n > 0)) {                       // offset 0 (corrupt streams only): keep what dst holds, 8 bytes at a time
+                uint64_t acc = 0;
+                for (int b = 0; b < n; b++) acc |= (uint64_t)dst[op + b] << (8 * b);
+                v0 = (uint32_t)acc; v1 = (uint32_t)(acc >> 32);
+            }
+            ip += lit ? n : 0;
+            L4_APPEND(v0, v1, v2, v3, n, true);
+            rem = rem_after;
+            off = (near & (off < 16) & (n > 0)) ? off * 2 : off;
+            kind = rem == 0 ? (int)kK4None : kind;
+        }
+
+        // ---- (B4) promote the parsed-ahead sequence: its inline literals, then its copy becomes the current one ----
+        {
+            const bool promote = (rem == 0) & (pv != 0) & room;
+            const bool perr = promote & ((p_flags & kF4Err) != 0);
+            const bool pgo = promote & !perr;
+            L4_APPEND(p_l0, p_l1, p_l2, 0u, pgo ? p_ll : 0, false);
+            if (perr) {                                              // corrupt stream: this lane is finished, nothing more is stored
+                done = 1; final_seen = 1; final_run = 0; result = p_res;
+            }
+            if (pgo) {
+                const bool streamed = p_st > 0;
+                rem = streamed ? p_st : p_ml;
+                off = streamed ? off : p_off;
+                kind = streamed ? (int)kK4Lit : (p_ml == 0 ? (int)kK4None : (p_off == 0 ? (int)kK4Zero : (p_off <= kNearMax ? (int)kK4Near : (int)kK4Far)));
+                final_run = (p_flags & kF4Final) ? 1 : final_run;
+                result = (p_flags & kF4Final) ? p_res : result;
+            }
+            pv = promote ? 0 : pv;
+        }
+
+        // ---- (B5) end of block: write out the last bytes exactly ----
+        if (final_run && rem == 0 && !pv && !done) {
+            uint32_t qa = ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu));
+            while (op - fl >= 4) { const uint32_t qd = L4_RING(qa); __builtin_memcpy(dst + fl, &qd, 4); fl += 4; qa = ring_add(qa, 256u); }
+            if (fl < op) {
+                const uint32_t qd = L4_RING(qa);
+                for (int b = 0; fl + b < op; b++) dst[fl + b] = (uint8_t)(qd >> (8 * b));
+            }
+            done = 1;
+        }
+        return !wv::any(done == 0);                                  // every lane of the wavefront is finished
+    };
+
+    for (;;) {
+        if (iteration(fa, fb, pend_a, pend_b)) break;
+        if (iteration(fb, fa, pend_b, pend_a)) break;
+    }
+    return result;
+#undef L4_RING
+#undef L4_PHASE_SEL
+#undef L4_APPEND
+}
+
+// One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
+template <bool KNOWN, int R, int P, int FU, int POL = 0>
+__global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
+{
+    LZ4HIP_STATIC_LDS(lds, lane4_lds_bytes(R));
+    const int lane = (int)threadIdx.x;
+    const int64_t blk = (int64_t)blockIdx.x * 64 + lane;
+    bool active = blk < b.n_blocks;
+    int src_len = 0, out_size = 0;
+    if (active) {
+        src_len = batch_src_len(b, blk); out_size = batch_dst_cap(b, blk);
+        active = block_selected(filter, src_len, out_size);
+    }
+    if (!wv::any(active)) return;
+    const uint8_t* src = active ? batch_src(b, blk) : nullptr;
+    uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
+    const int r = lane4_decode_block<KNOWN, R, P, FU, POL>(lds, lane, active, src, src_len, dst, out_size);
+    if (active) b.result[blk] = r;
+}
+
+}  // namespace lz4hip

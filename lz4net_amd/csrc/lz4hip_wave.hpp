@@ -146,6 +146,30 @@ LZ4HIP_DEVICE void vm_wait(u32x4& a, u32x4& b)
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N) : "memory");
 }
 
+// The same wait for a loop that keeps more load destinations: `a` and every element of `l` may not be read before.
+template <int N, int M>
+LZ4HIP_DEVICE void vm_wait_list(u32x4& a, u32x4 (&l)[M])
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a) : [n] "n"(N) : "memory");
+#pragma unroll
+    for (int j = 0; j < M; j++) asm volatile("" : "+v"(l[j]));
+}
+
+// ---- per-lane selects that STAY selects (lz4hip_decode_lane4.hpp) ----------------------------------------------------------
+// A binary tree of `c ? a[i + k] : a[i]` over a register array is how a lane takes bytes at a per-lane position out of a
+// window it keeps in registers.  Written in plain C++ the compiler recognises a dynamically indexed array and moves the array
+// to scratch memory (measured: 4 000 cycles per lookup, tools/microbench_select_tree.hip); v_cndmask_b32 through inline
+// assembly keeps it in registers (4.5 cycles per select).  cond() turns the per-lane condition into the lane mask once.
+typedef uint64_t mask_t;
+LZ4HIP_DEVICE mask_t cond(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+LZ4HIP_DEVICE uint32_t sel(mask_t m, uint32_t a, uint32_t b)      // m ? a : b
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 // DS_MSKOR_B32: MEM = (MEM & ~mask) | data -- a byte-granular merge into an aligned LDS dword without reading it back.
 // (An LDS instruction the compiler does not know about only makes its own lgkmcnt waits stricter: LDS operations of a
 // wavefront complete in issue order.)

@@ -21,7 +21,7 @@ def build(starved: bool = False) -> str:
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         flags = ["-DLZ4HIP_HAVE_HC", "-DLZ4HIP_TUNING_BUILD"] if os.path.exists(os.path.join(CSRC, "lz4hip_hc.hpp")) else []
         if starved:
-            flags += ["-DLZ4HIP_DEC_FLUSH_RECS=4", "-DLZ4HIP_DEC_LOAD_PIECES=2", "-DLZ4HIP_DEC3_FLUSH_RECS=4", "-DLZ4HIP_DEC3_LOAD_PIECES=2"]
+            flags += ["-DLZ4HIP_DEC_FLUSH_RECS=4", "-DLZ4HIP_DEC_LOAD_PIECES=2", "-DLZ4HIP_DEC3_FLUSH_RECS=4", "-DLZ4HIP_DEC3_LOAD_PIECES=2", "-DLZ4HIP_DEC4_FLUSH_RECS=2"]
         subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused", "-Wno-parentheses", "-Wno-unknown-pragmas",
                         "-I" + HERE, "-I" + CSRC, *flags, "-o", so, os.path.join(HERE, "emu_kernels.cpp")],
                        check=True)

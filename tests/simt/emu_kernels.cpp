@@ -10,6 +10,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #include "lz4hip_decode.hpp"
 #include "lz4hip_decode_lane.hpp"
 #include "lz4hip_decode_lane3.hpp"
+#include "lz4hip_decode_lane4.hpp"
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_synth.hpp"
@@ -82,6 +83,30 @@ void emu_decode_lane3(int known, const uint8_t* src, int64_t src_stride, const i
     else if (ring == 256) EMU_LANE3(256, 64);
     else simt::die("emu_decode_lane3: ring size not instantiated", ring, stage);
 #undef EMU_LANE3
+}
+
+// fourth-generation lane decoder (lz4hip_decode_lane4.hpp); cfg = ring bytes + 1000 x variant (bit 0: 128-byte flush units, bit 1: 32-byte pieces)
+void emu_decode_lane4(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                      int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int cfg)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+#define EMU_LANE4(R, P, FU)                                                                                                     \
+    do {                                                                                                                        \
+        if (known) simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<true, R, P, FU>(b, filter); });         \
+        else       simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<false, R, P, FU>(b, filter); });        \
+    } while (0)
+    switch (cfg) {
+    case 128: EMU_LANE4(128, 64, 64); break;
+    case 2128: EMU_LANE4(128, 32, 64); break;
+    case 192: EMU_LANE4(192, 64, 64); break;
+    case 1192: EMU_LANE4(192, 64, 128); break;
+    case 3192: EMU_LANE4(192, 32, 128); break;
+    case 1256: EMU_LANE4(256, 64, 128); break;
+    case 2240: EMU_LANE4(240, 32, 64); break;
+    default: simt::die("emu_decode_lane4: configuration not instantiated", cfg, 0);
+    }
+#undef EMU_LANE4
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

@@ -153,6 +153,11 @@ inline void vm_wait(u32x4&, u32x4&)
         if (op.is_load && op.addr) __builtin_memcpy(op.dst, (const void*)op.addr, 16);
     }
 }
+template <int N, int M>
+inline void vm_wait_list(u32x4& a, u32x4 (&l)[M]) { u32x4 dummy{}; vm_wait<N>(a, dummy); }
+typedef bool mask_t;
+inline mask_t cond(bool p) { return p; }
+inline uint32_t sel(mask_t m, uint32_t a, uint32_t b) { return m ? a : b; }
 inline void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data) { *p = (*p & ~mask) | data; }
 
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }

@@ -12,6 +12,8 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
+    if isinstance(m, str) and m.startswith("l4c"):                   # "l4c1192": fourth-generation lane decoder, ring 192 + 1000 x variant
+        return dict(lane=int(m[3:]), gen=4)
     if isinstance(m, str) and m.startswith("l3r"):                   # "l3r240": third-generation lane decoder, ring 240 (staging 64)
         ring, _, stage = m[3:].partition("s")
         return dict(lane=int(ring), stage=int(stage or 64), gen=3)
@@ -21,8 +23,8 @@ def _mapping(m):
     return {}
 
 
-LANE3 = ["l3r128", "l3r240"]    # third generation (the product's lane decoder): a power-of-two ring and another one
-LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128"]
+LANE3 = ["l3r128", "l3r240", "l4c1192", "l4c2128"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
+LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128", "l4c128", "l4c2128", "l4c192", "l4c1192", "l4c3192", "l4c1256", "l4c2240"]
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
@@ -393,7 +395,7 @@ def test_lane_decoder_lockstep_lanes_and_copy_lengths(oracle, mapping):
             assert np.array_equal(dst[i, :block.size], block), (known, i)
 
 
-@pytest.mark.parametrize("gen", [3])
+@pytest.mark.parametrize("gen", [3, 4])
 def test_lane_decoder_starved_flush(oracle, gen):
     """The lane decoder with its cooperative flush cut down to 4 lines per round: with 64 busy lanes most of them miss
     flush rounds several times in a row, run their output rings full and sit out iterations -- also while the first or the
@@ -416,13 +418,13 @@ def test_lane_decoder_starved_flush(oracle, gen):
             comps = [oracle.compress(a) for a in blocks]
             for known in (True, False):
                 res, dst = emu.decode([np.concatenate([c, np.zeros(64, np.uint8)]) for c in comps], [a.size for a in blocks], known=known,
-                                      src_lens=None if known else [len(c) for c in comps], lane=128, stage=64, gen=gen)
+                                      src_lens=None if known else [len(c) for c in comps], lane=1192 if gen == 4 else 128, stage=64, gen=gen)
                 for i, (a, c) in enumerate(zip(blocks, comps)):
                     assert res[i] == (len(c) if known else a.size), (known, i, res[i])
                     assert np.array_equal(dst[i, :a.size], a), (known, i)
         # the odd-but-legal and malformed streams and the error-code matrix, in the same starved state
-        test_decode_arbitrary_streams(oracle, "lane128s64" if gen == 2 else "l3r128")
-        test_decode_error_codes_match_oracle(oracle, "lane128s64" if gen == 2 else "l3r128")
+        test_decode_arbitrary_streams(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c1192"}[gen])
+        test_decode_error_codes_match_oracle(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c1192"}[gen])
 
 
 @pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)

@@ -21,7 +21,7 @@ for dist in dists:
     _lib.tuning_set("decoder", "lane")
     for gen, ring in cfgs:
         _lib.tuning_set("decoder_gen", gen)
-        _lib.tuning_set("decoder_ring", ring if gen == 3 else 0)
+        _lib.tuning_set("decoder_ring", ring if gen >= 3 else 0)
         try:
             back.zero_()
             batch.decode(comp, clen, back, batch.BLOCK, result=used)
