@@ -78,6 +78,9 @@ def parse_args():
                     help="block->hardware mapping of the decoder (auto = library default)")
     ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
+    ap.add_argument("--early-workspace", type=int, default=0,
+                    help="1: allocate the lane encoder's table slab BEFORE the batch buffers; 0 (default): when first needed -- measured: the early "
+                         "slab is the SLOW placement (44-46 GB/s in 5 of 6 fresh processes, late 53-54 in 5 of 6; profiles/r04/encoder_reproducibility.txt)")
     ap.add_argument("--verify-budget", type=float, default=45.0,
                     help="seconds of host time for EACH full-corpus encoder check against the CPU reference (0 = skip)")
     return ap.parse_args()
@@ -302,6 +305,17 @@ def main():
     seed = args.seed
     _lib.tuning_set("decoder", args.decoder)
     _lib.tuning_set("encoder", args.encoder)
+    if args.early_workspace:
+        # (experiment, off by default) The lane encoder keeps one 32 KiB table per resident lane in a slab that the library allocates
+        # when a batch first needs it.  A batch of tiny blocks, large enough for the full residency, makes the library allocate
+        # it now, before the 192 GB of batch buffers -- which turned out to be the slower placement.
+        tiny_n, tiny_len = 1 << 19, 64
+        tiny = batch.synth(2, 1, 0, tiny_n, length=tiny_len)
+        tiny_out = torch.empty((tiny_n, 96), dtype=torch.uint8, device="cuda")
+        batch.encode(tiny, tiny_len, tiny_out, 80)
+        torch.cuda.synchronize()
+        del tiny, tiny_out
+        torch.cuda.empty_cache()
     wl = Workload(torch, batch, args.dist, seed, rank, n, block_step=world, dst_pad=args.dst_pad)
     for _ in range(max(args.warmup, 0)):
         wl.decode_step()
@@ -572,7 +586,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if wave_mapped
-                       else "lz4hip::decode_lane3_kernel<true,128,64,0> (one lane per block, LDS input staging + output ring, hand-counted vmcnt)"),
+                       else "lz4hip::decode_lane4_kernel<true,192,32,128,1,0> (one lane per block: input window in registers, 192-byte LDS output ring, 128-byte flush units, hand-counted vmcnt)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

@@ -104,7 +104,7 @@ int lz4hip_decode_batch_host_multi(const lz4hip_batch_t* b, int known_output_siz
  * Launch counters per kernel family since the library was loaded: which block->hardware mapping a call
  * actually used (the GPU tests assert these).  Copies min(n, LZ4HIP_K_COUNT) counters, returns LZ4HIP_K_COUNT. */
 #define LZ4HIP_K_DECODE_WAVE 0   /* lz4hip_decode.hpp:         one wavefront per block */
-#define LZ4HIP_K_DECODE_LANE 1   /* lz4hip_decode_lane.hpp:    one lane per block      */
+#define LZ4HIP_K_DECODE_LANE 1   /* lz4hip_decode_lane4.hpp:   one lane per block      */
 #define LZ4HIP_K_ENCODE_WAVE 2
 #define LZ4HIP_K_ENCODE_LANE 3
 #define LZ4HIP_K_HC_WAVE     4
@@ -119,16 +119,21 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *   "encoder_waves_per_cu", "hc_waves_per_cu"  [LZ4HIP_ENCODER_WAVES_PER_CU, LZ4HIP_HC_WAVES_PER_CU]  residency of the
  *                                 persistent lane-per-block encoder grids (0 = built-in default)
  *   "hc_groups"                  [LZ4HIP_HC_GROUPS]  wavefronts of the LZ4HC lane grid (0 = from the residency)
- *   "host_threads", "host_slices" [LZ4HIP_HOST_THREADS, LZ4HIP_HOST_SLICES]  host-pointer batches: gather/scatter threads, slices per batch
- *   "decoder_gen", "decoder_ring" [LZ4HIP_DECODER_GEN, LZ4HIP_DECODER_RING]  lane decoder generation (0 default, 2, 3) and, for
- *                                 generation 3, the bytes of output ring per lane (0 default; other sizes exist only in
- *                                 libraries built with -DLZ4HIP_TUNING_BUILD)
+ *   "host_threads", "host_slices" [LZ4HIP_HOST_THREADS, LZ4HIP_HOST_SLICES]  host-pointer batches: threads of the process-wide row pool that gathers /
+ *                                 scatters rows (0 = min(hardware threads / 4, 64); read when the pool starts a thread), slices per batch
+ *   "decoder_gen", "decoder_ring" [LZ4HIP_DECODER_GEN, LZ4HIP_DECODER_RING]  lane decoder generation (0 default = 4, lz4hip_decode_lane4.hpp;
+ *                                 2 and 3 exist only in libraries built with -DLZ4HIP_TUNING_BUILD) and, for generation 4, its
+ *                                 configuration: bytes of output ring per lane + 1000 x variant (bit 0: 128-byte flush units,
+ *                                 bit 1: 32-byte input pieces, bit 2: one flush store instruction per iteration; 0 = default 7192;
+ *                                 other configurations exist only in tuning builds)
  *   "hc_gen"                     [LZ4HIP_HC_GEN]  LZ4HC lane mapping: 0 default (4 for blocks <= 64 KiB, else 2); 4 the state machine over
  *                                 precomputed chains that carry shared lengths (lz4hip_hc_lcp.hpp), 2 the state machine with the
  *                                 insert loop (lz4hip_hc_conv.hpp: blocks > 64 KiB; smaller ones only in tuning builds); 1 and 3 (one
  *                                 loop nest per lane; precomputed chains without lengths) exist only in -DLZ4HIP_TUNING_BUILD libraries
  *   "hc_ctrl_every", "hc_ctrl_lanes" [LZ4HIP_HC_CTRL_EVERY, LZ4HIP_HC_CTRL_LANES]  generation 4: the parse's control flow runs for all
  *                                 waiting lanes every N-th iteration (a power of two) or as soon as M lanes wait (0 = defaults 8 / 32)
+ *   "hc_sub_chunks"              [LZ4HIP_HC_SUB_CHUNKS]  LZ4HC lane mapping, blocks <= 64 KiB: a chunk of blocks is cut into this many sub-chunks whose
+ *                                 table builders and lane kernels overlap on separate streams (0 = default 2, 1 = one after the other, at most 8)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

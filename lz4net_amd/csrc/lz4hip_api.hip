@@ -6,13 +6,16 @@
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
-#include "lz4hip_decode_lane.hpp"
-#include "lz4hip_decode_lane3.hpp"
 #include "lz4hip_decode_lane4.hpp"
+#ifdef LZ4HIP_TUNING_BUILD            /* superseded generations, for same-box A/B runs only (tools/ab/) */
+#include "../../tools/ab/lz4hip_decode_lane.hpp"
+#include "../../tools/ab/lz4hip_decode_lane3.hpp"
+#include "../../tools/ab/lz4hip_hc_lane.hpp"
+#include "../../tools/ab/lz4hip_hc_nat_lane.hpp"
+#endif
 #include "lz4hip_encode.hpp"
 #include "lz4hip_encode_lane.hpp"
 #include "lz4hip_hc.hpp"
-#include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
 #include "lz4hip_hc_nat.hpp"
 #include "lz4hip_hc_lcp.hpp"
@@ -22,6 +25,8 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -45,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -53,10 +58,11 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "hc_groups", "LZ4HIP_HC_GROUPS", false },                     // persistent grid of the LZ4HC lane kernel (tests: few lanes, many blocks each)
     { "host_threads", "LZ4HIP_HOST_THREADS", false }, { "host_slices", "LZ4HIP_HOST_SLICES", false },
     { "logical_devices", "LZ4HIP_LOGICAL_DEVICES", false },         // tests: N workers of the multi-device path over the visible devices (wrapping around)
-    { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default, 2 lz4hip_decode_lane.hpp, 3 lz4hip_decode_lane3.hpp
-    { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 3: bytes of output ring per lane (0 default; other sizes only in LZ4HIP_TUNING_BUILD libraries)
+    { "decoder_gen", "LZ4HIP_DECODER_GEN", false },                 // lane decoder: 0 default = 4 lz4hip_decode_lane4.hpp; 2 and 3 (tools/ab/) only in LZ4HIP_TUNING_BUILD libraries
+    { "decoder_ring", "LZ4HIP_DECODER_RING", false },               // generation 4: ring bytes + 1000 x variant (0 default; other configurations only in LZ4HIP_TUNING_BUILD libraries)
     { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default; 4 lz4hip_hc_lcp.hpp (blocks <= 64 KiB), 2 lz4hip_hc_conv.hpp (larger blocks; <= 64 KiB in tuning builds); 1 lz4hip_hc_lane.hpp and 3 lz4hip_hc_nat.hpp in tuning builds only
     { "hc_ctrl_every", "LZ4HIP_HC_CTRL_EVERY", false }, { "hc_ctrl_lanes", "LZ4HIP_HC_CTRL_LANES", false },   // lz4hip_hc_lcp.hpp: control-flow batching (0 default)
+    { "hc_sub_chunks", "LZ4HIP_HC_SUB_CHUNKS", false },             // LZ4HC lane launch: sub-chunks whose table builders and lane kernels overlap (0 default = 2, 1 = one after the other, max 8)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -78,9 +84,8 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 // batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
-constexpr int kLaneDecodeRingBytes = 128, kLaneDecodeStageBytes = 64;
-constexpr int kLaneDecodeGeneration = 3, kLane3RingBytes = 128;
-constexpr int kLane4Config = 1192;           // generation 4: 192-byte ring, 64-byte input pieces, 128-byte flush units
+constexpr int kLaneDecodeGeneration = 4;
+constexpr int kLane4Config = 7192;           // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units, one flush store instruction per iteration
 constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
@@ -167,6 +172,14 @@ struct Lease {
     HcWorkspace* w = nullptr;
     std::unique_lock<std::mutex> lock;
     void* p = nullptr;
+    hipStream_t stream = nullptr;
+    bool queued = false;         // kernels that use the workspace have been queued on `stream`
+    // An error return between the first launch and lease_end() must not leave those kernels unaccounted for: the next user
+    // (possibly on another stream) would overwrite tables that are still being read.
+    ~Lease()
+    {
+        if (w && lock.owns_lock() && queued && w->last && hipEventRecord(w->last, stream) == hipSuccess) w->busy = true;
+    }
 };
 
 // Takes the lock on the device's workspace and makes `stream` wait for its previous user.
@@ -176,6 +189,7 @@ int lease_begin(HcWorkspace* pool, hipStream_t stream, Lease& l)
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
     l.w = &pool[dev];
+    l.stream = stream;
     l.lock = std::unique_lock<std::mutex>(l.w->mu);
     if (!l.w->last) HIP_TRY(hipEventCreateWithFlags(&l.w->last, hipEventDisableTiming));
     if (l.w->busy) HIP_TRY(hipStreamWaitEvent(stream, l.w->last, 0));
@@ -196,11 +210,36 @@ int lease_reserve(Lease& l, size_t bytes)
 // Everything queued on `stream` so far is this user's work on the workspace.
 int lease_end(Lease& l, hipStream_t stream)
 {
+    l.queued = false;                                                // (recorded here; nothing left for the destructor)
     HIP_TRY(hipEventRecord(l.w->last, stream));
     l.w->busy = true;
     l.lock.unlock();
     return 0;
 }
+
+// Streams and events of the pipelined LZ4HC lane launch (one set per device, created on first use; the workspace lease
+// serialises its users).
+constexpr int kHcSubChunks = 2, kHcMaxSubChunks = 8;   // measured at 2^18 blocks (profiles/r04/hc_sub_chunks.txt): 1 -> 15.9 / 20.8 GB/s (D2 / D3), 2 -> 16.8 / 23.2, 4 -> 15.1 / 21.0, 8 -> 11.6 / 16.7
+constexpr size_t kHcCounterBytes = 256 * kHcMaxSubChunks;
+struct HcPipe {
+    bool ready = false;
+    hipStream_t build = nullptr, lane[kHcMaxSubChunks];
+    hipEvent_t start = nullptr, built[kHcMaxSubChunks], done[kHcMaxSubChunks];
+    int init()
+    {
+        if (ready) return 0;
+        HIP_TRY(hipStreamCreateWithFlags(&build, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+        for (int k = 0; k < kHcMaxSubChunks; k++) {
+            HIP_TRY(hipStreamCreateWithFlags(&lane[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&built[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        ready = true;
+        return 0;
+    }
+};
+HcPipe g_hc_pipe[64];
 
 int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
 {
@@ -244,6 +283,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             count_dispatch(LZ4HIP_K_ENCODE_WAVE);
         }
         if (pick != 'w') {
+            lease.queued = true;
             HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
             hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
                                (unsigned long long*)ws, (uint8_t*)ws + 256, pick == 'a' ? 1 : 0);
@@ -289,44 +329,106 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 chunk = groups * 64 < 4096 ? 4096 : groups * 64;
                 const int64_t n_chunks = (d.n_blocks + chunk - 1) / chunk;
                 chunk = ((d.n_blocks + n_chunks - 1) / n_chunks + 63) / 64 * 64;
-                const size_t bytes = hc_gen == 4 ? (size_t)chunk * kHcLcpTableBytes : hc_gen == 3 ? (size_t)chunk * kHcNatChainBytes : (size_t)groups * 64 * slab;
-                if (lease_reserve(lease, bytes + 256) == 0) { ws = lease.p; break; }
+                if (hc_gen >= 3) {
+                    // tables: 256 KiB (generation 4) per block of a chunk, rebuilt chunk after chunk -- never more than half of what the
+                    // device has free (a 2^18-block chunk is 64 GiB), and a chunk that cannot be had is halved, down to 4096 blocks
+                    const size_t entry = hc_gen == 4 ? kHcLcpTableBytes : kHcNatChainBytes;
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+                    const size_t budget = (free_b + lease.w->cap) / 2;
+                    int64_t c = chunk;
+                    while (c > 4096 && (size_t)c * entry > budget) c = (c / 2 + 63) / 64 * 64;
+                    for (;;) {
+                        if (lease_reserve(lease, (size_t)c * entry + kHcCounterBytes) == 0) { ws = lease.p; chunk = c; break; }
+                        if (c <= 4096) break;
+                        c = (c / 2 + 63) / 64 * 64;
+                    }
+                    if (ws || knob(kKnobHcGroups) > 0) break;
+                    continue;
+                }
+                const size_t bytes = (size_t)groups * 64 * slab;
+                if (lease_reserve(lease, bytes + kHcCounterBytes) == 0) { ws = lease.p; break; }
             }
             if (ws && hc_gen >= 3) {
-                // lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp: per chunk, the table builders (one workgroup per block), then the lane kernel
+                // lz4hip_hc_nat.hpp / lz4hip_hc_lcp.hpp: per chunk, the table builders (one workgroup per block), then the lane kernel.
+                // The builders need LDS and few registers, the lane kernel registers and no LDS, so they overlap well -- but one
+                // after the other on one stream they did not overlap at all (round 3: 190 ms of builders in front of 850 ms of lane
+                // kernel).  A chunk is therefore cut into up to kHcSubChunks SUB-CHUNKS: the builders run through them on a build
+                // stream, and the lane kernel of a sub-chunk starts on its own stream as soon as its tables are there -- next to the
+                // builders of the following ones and to the lane kernels of the earlier ones (each takes its share of the persistent
+                // grid).  Same tables, same bytes; the table memory is what one chunk needs, as before.
                 if (hc_gen == 4) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)hc_lcp_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHcLcpFillLdsBytes));
+                    static std::atomic<bool> attr_set[64];            // once per device, not per launch
+                    if (!attr_set[dev].load(std::memory_order_acquire)) {
+                        HIP_TRY(hipFuncSetAttribute((const void*)hc_lcp_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHcLcpFillLdsBytes));
+                        attr_set[dev].store(true, std::memory_order_release);
+                    }
                 }
+                HcPipe& hp = g_hc_pipe[dev];
+                if ((rc = hp.init())) return rc;
+                const size_t entry = hc_gen == 4 ? kHcLcpTableBytes : kHcNatChainBytes;
+                uint8_t* const tables = (uint8_t*)ws + kHcCounterBytes;
+                lease.queued = true;
+                HIP_TRY(hipMemsetAsync(ws, 0, kHcCounterBytes, stream));          // one work counter per sub-chunk (256 bytes apart)
                 for (int64_t first = 0; first < d.n_blocks; first += chunk) {
                     const int64_t cnt = d.n_blocks - first < chunk ? d.n_blocks - first : chunk;
-                    int64_t g = (cnt + 63) / 64 < groups ? (cnt + 63) / 64 : groups;
-                    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-                    if (hc_gen == 4) {
-                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint32_t>, dim3((unsigned)cnt), dim3(kHcNatChainThreads), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
-                        HIP_TRY(hipGetLastError());
-                        hipLaunchKernelGGL(hc_lcp_fill_kernel, dim3((unsigned)cnt), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
-                        HIP_TRY(hipGetLastError());
-                        int every = knob(kKnobHcCtrlEvery) > 0 ? knob(kKnobHcCtrlEvery) : kHcLcpCtrlEvery;
-                        while (every & (every - 1)) every &= every - 1;          // (a power of two)
-                        const int lanes = knob(kKnobHcCtrlLanes) > 0 ? knob(kKnobHcCtrlLanes) : kHcLcpCtrlLanes;
-                        hipLaunchKernelGGL(encode_hc_lcp_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
-                                           (unsigned long long*)ws, (uint8_t*)ws + 256, every, lanes);
-                    } else {
+                    int subs = knob(kKnobHcSubChunks) > 0 ? knob(kKnobHcSubChunks) : kHcSubChunks;
+                    subs = subs > kHcMaxSubChunks ? kHcMaxSubChunks : subs;
+                    while (subs > 1 && cnt / subs < 4096) subs--;              // (a lane-mapped launch of fewer blocks is all latency)
+                    const int64_t per = ((cnt + subs - 1) / subs + 63) / 64 * 64;
+                    // everything queued on the caller's stream so far (the previous chunk's lane kernels included: they read the
+                    // tables that are rebuilt now, and the counters that are zeroed again) comes first
+                    if (first > 0) HIP_TRY(hipMemsetAsync(ws, 0, kHcCounterBytes, stream));
+                    HIP_TRY(hipEventRecord(hp.start, stream));
+                    HIP_TRY(hipStreamWaitEvent(hp.build, hp.start, 0));
+                    int used = 0;
+                    for (int64_t s0 = 0; s0 < cnt; s0 += per, used++) {
+                        const int64_t sc = cnt - s0 < per ? cnt - s0 : per;
+                        uint8_t* const tab = tables + (size_t)s0 * entry;
+                        hipStream_t ls = subs > 1 ? hp.lane[used] : stream;
+                        hipStream_t bs = subs > 1 ? hp.build : stream;
+                        if (hc_gen == 4) {
+                            hipLaunchKernelGGL(hc_nat_chain_kernel<uint32_t>, dim3((unsigned)sc), dim3(kHcNatChainThreads), kHcNatLdsBytes, bs, d, (long long)(first + s0), tab);
+                            HIP_TRY(hipGetLastError());
+                            hipLaunchKernelGGL(hc_lcp_fill_kernel, dim3((unsigned)sc), dim3(kHcLcpFillThreads), kHcLcpFillLdsBytes, bs, d, (long long)(first + s0), tab);
+                            HIP_TRY(hipGetLastError());
+                        } else {
 #ifdef LZ4HIP_TUNING_BUILD
-                        hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)cnt), dim3(kHcNatChainThreads), kHcNatLdsBytes, stream, d, (long long)first, (uint8_t*)ws + 256);
-                        HIP_TRY(hipGetLastError());
-                        hipLaunchKernelGGL(encode_hc_nat_kernel, dim3((unsigned)g), dim3(64), 0, stream, d, (long long)first, (long long)cnt,
-                                           (unsigned long long*)ws, (uint8_t*)ws + 256);
+                            hipLaunchKernelGGL(hc_nat_chain_kernel<uint16_t>, dim3((unsigned)sc), dim3(kHcNatChainThreads), kHcNatLdsBytes, bs, d, (long long)(first + s0), tab);
+                            HIP_TRY(hipGetLastError());
 #else
-                        return fail(LZ4HIP_E_ARGUMENT, "hc_gen: this library has no LZ4HC lane kernel of that generation");
+                            return fail(LZ4HIP_E_ARGUMENT, "hc_gen: this library has no LZ4HC lane kernel of that generation");
 #endif
+                        }
+                        if (subs > 1) {
+                            HIP_TRY(hipEventRecord(hp.built[used], hp.build));
+                            HIP_TRY(hipStreamWaitEvent(ls, hp.built[used], 0));
+                            HIP_TRY(hipStreamWaitEvent(ls, hp.start, 0));        // (the counters' memset, the caller's earlier work)
+                        }
+                        int64_t g = (sc + 63) / 64 < groups ? (sc + 63) / 64 : groups;
+                        unsigned long long* const counter = (unsigned long long*)((uint8_t*)ws + 256 * (size_t)used);
+                        if (hc_gen == 4) {
+                            int every = knob(kKnobHcCtrlEvery) > 0 ? knob(kKnobHcCtrlEvery) : kHcLcpCtrlEvery;
+                            while (every & (every - 1)) every &= every - 1;          // (a power of two)
+                            const int lanes = knob(kKnobHcCtrlLanes) > 0 ? knob(kKnobHcCtrlLanes) : kHcLcpCtrlLanes;
+                            hipLaunchKernelGGL(encode_hc_lcp_kernel, dim3((unsigned)g), dim3(64), 0, ls, d, (long long)(first + s0), (long long)sc,
+                                               counter, tab, every, lanes);
+                        }
+#ifdef LZ4HIP_TUNING_BUILD
+                        else hipLaunchKernelGGL(encode_hc_nat_kernel, dim3((unsigned)g), dim3(64), 0, ls, d, (long long)(first + s0), (long long)sc, counter, tab);
+#endif
+                        HIP_TRY(hipGetLastError());
+                        if (subs > 1) {
+                            HIP_TRY(hipEventRecord(hp.done[used], ls));
+                            HIP_TRY(hipStreamWaitEvent(stream, hp.done[used], 0));   // the caller's stream ends up behind every sub-chunk
+                        }
                     }
-                    HIP_TRY(hipGetLastError());
                 }
                 count_dispatch(LZ4HIP_K_HC_LANE);
                 return lease_end(lease, stream);
             }
             if (ws) {
+                lease.queued = true;
                 HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
                 if (hc_gen == 2 && !small)
                     hipLaunchKernelGGL(encode_hc_conv_kernel<uint32_t>, dim3((unsigned)groups), dim3(64), 0, stream, d,
@@ -351,6 +453,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         if ((rc = lease_reserve(lease, (size_t)groups * kHcGlobalBytesPerGroup + 256))) return rc;
         void* ws = lease.p;
         // first 8 bytes of the workspace: the work counter of the persistent grid
+        lease.queued = true;
         HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
         if (!small) HIP_TRY(hipFuncSetAttribute((const void*)encode_hc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(encode_hc_kernel, dim3((unsigned)groups), dim3(64), lds_bytes, stream, d,
@@ -370,7 +473,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     if (b->n_blocks == 0) return 0;
     const Batch d = to_device_batch(*b);
     // Two mappings of the same decoder (lz4hip_decode.hpp: one wavefront per block, coalesced wide copies;
-    // lz4hip_decode_lane.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
+    // lz4hip_decode_lane4.hpp: one lane per block, 64 blocks in flight per wavefront).  A batch is
     // partitioned per block by block_selected(): two launches, each skipping the other's blocks.
     // Small batches cannot fill the lanes and use the wavefront mapping only.
     // The "decoder" knob (LZ4HIP_DECODER=wave|lane at load time, lz4hip_tuning_set) forces one mapping for EVERY block,
@@ -382,76 +485,51 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
     else if (d.n_blocks < kLaneDecodeMinBlocks) { wave_filter = kAllBlocks; lane_filter = -1; }
     if (lane_filter >= 0) {
         const unsigned grid = (unsigned)((d.n_blocks + 63) / 64);
-        // LDS per wavefront = 64 x (ring + staging) + 1 KiB decides the residency (128 + 64: 12 wavefronts per CU; the
-        // other ring / staging sizes that were measured are in profiles/r02/decoder_ab_*.txt).
+        // Generation 4 (lz4hip_decode_lane4.hpp): LDS per wavefront = 64 x ring + 256..512 bytes decides the residency (ring 192:
+        // 12 wavefronts per CU); the configurations that were measured are in profiles/r04/decoder_gen4_*.txt.
         const int gen = knob(kKnobDecoderGen) ? knob(kKnobDecoderGen) : kLaneDecodeGeneration;
-#ifdef LZ4HIP_TUNING_BUILD                                              /* round-2 kernel, for A/B runs (tools/ab_decoder_knobs.py) */
-        if (gen == 2) {
-            constexpr int R = kLaneDecodeRingBytes, SB = kLaneDecodeStageBytes;
-            if (known) hipLaunchKernelGGL((decode_lane_kernel<true, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
-            else       hipLaunchKernelGGL((decode_lane_kernel<false, R, SB>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
-        } else
-#endif
         if (gen == 4) {
-            // generation 4 (lz4hip_decode_lane4.hpp): input window in registers.  decoder_ring = ring bytes + 1000 x variant
-            // (variant 0: 64-byte pieces, 64-byte flush units; 1: 64 / 128; 2: 32 / 64; 3: 32 / 128)
+            // decoder_ring = ring bytes + 1000 x variant (variant bit 0: 128-byte flush units, bit 1: 32-byte input pieces,
+            // bit 2: one flush store instruction per iteration)
             const int cfg = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane4Config;
-#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH)                                                                                 \
+#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS)                                                                             \
             do {                                                                                                                \
-                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
-                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
             } while (0)
+#define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2); break
             switch (cfg) {
-            case kLane4Config: LZ4HIP_LAUNCH_LANE4(kLane4Config % 1000, (kLane4Config / 1000 & 2) ? 32 : 64, (kLane4Config / 1000 & 1) ? 128 : 64); break;
-#ifdef LZ4HIP_TUNING_BUILD
-            case 128: LZ4HIP_LAUNCH_LANE4(128, 64, 64); break;
-            case 2128: LZ4HIP_LAUNCH_LANE4(128, 32, 64); break;
-            case 192: LZ4HIP_LAUNCH_LANE4(192, 64, 64); break;
-            case 2192: LZ4HIP_LAUNCH_LANE4(192, 32, 64); break;
-            case 3192: LZ4HIP_LAUNCH_LANE4(192, 32, 128); break;
-            case 256: LZ4HIP_LAUNCH_LANE4(256, 64, 64); break;
-            case 1256: LZ4HIP_LAUNCH_LANE4(256, 64, 128); break;
-            case 3256: LZ4HIP_LAUNCH_LANE4(256, 32, 128); break;
-            case 1240: LZ4HIP_LAUNCH_LANE4(240, 64, 128); break;
+            LZ4HIP_LANE4_CASE(kLane4Config);
+#ifdef LZ4HIP_TUNING_BUILD                                              /* residency / ring / piece / flush-unit sweeps (tools/ab_decoder_knobs.py) */
+            LZ4HIP_LANE4_CASE(128); LZ4HIP_LANE4_CASE(2128); LZ4HIP_LANE4_CASE(6128); LZ4HIP_LANE4_CASE(3192); LZ4HIP_LANE4_CASE(192); LZ4HIP_LANE4_CASE(1192); LZ4HIP_LANE4_CASE(2192);
+            LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
 #endif
             default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
             }
+#undef LZ4HIP_LANE4_CASE
 #undef LZ4HIP_LAUNCH_LANE4
-        } else
-        if (gen != 3) return fail(LZ4HIP_E_ARGUMENT, "decoder_gen: this library has no lane decoder of that generation");
-        else {
-            const int ring = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane3RingBytes;
+        }
+#ifdef LZ4HIP_TUNING_BUILD                                              /* the generations it replaced (tools/ab/), for same-box A/B runs */
+        else if (gen == 2) {
+            if (known) hipLaunchKernelGGL((decode_lane_kernel<true, 128, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+            else       hipLaunchKernelGGL((decode_lane_kernel<false, 128, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter);
+        } else if (gen == 3) {
+            const int ring = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : 128;
 #define LZ4HIP_LAUNCH_LANE3(RING)                                                                                               \
             do {                                                                                                                \
                 if (known) hipLaunchKernelGGL((decode_lane3_kernel<true, RING, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
                 else       hipLaunchKernelGGL((decode_lane3_kernel<false, RING, 64>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
             } while (0)
-#define LZ4HIP_LAUNCH_LANE3_POL(RING, POL)                                                                                      \
-            do {                                                                                                                \
-                if (known) hipLaunchKernelGGL((decode_lane3_kernel<true, RING, 64, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
-                else       hipLaunchKernelGGL((decode_lane3_kernel<false, RING, 64, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
-            } while (0)
             switch (ring) {
-            case kLane3RingBytes: LZ4HIP_LAUNCH_LANE3(kLane3RingBytes); break;
-#ifdef LZ4HIP_TUNING_BUILD                                              /* residency vs near-window sweeps (tools/ab) */
-            case 1128: LZ4HIP_LAUNCH_LANE3_POL(128, 1); break;    // 1000 * policy + ring: far fetches nt / sc1 / sc0 sc1, input pieces nt
-            case 2128: LZ4HIP_LAUNCH_LANE3_POL(128, 2); break;
-            case 3128: LZ4HIP_LAUNCH_LANE3_POL(128, 3); break;
-            case 4128: LZ4HIP_LAUNCH_LANE3_POL(128, 4); break;
-            case 7128: LZ4HIP_LAUNCH_LANE3_POL(128, 7); break;
-            case 160: LZ4HIP_LAUNCH_LANE3(160); break;
-            case 176: LZ4HIP_LAUNCH_LANE3(176); break;
+            case 128: LZ4HIP_LAUNCH_LANE3(128); break;
             case 192: LZ4HIP_LAUNCH_LANE3(192); break;
             case 240: LZ4HIP_LAUNCH_LANE3(240); break;
-            case 256: LZ4HIP_LAUNCH_LANE3(256); break;
-            case 272: LZ4HIP_LAUNCH_LANE3(272); break;
-            case 368: LZ4HIP_LAUNCH_LANE3(368); break;
-#endif
-            default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no lane decoder with that ring size");
+            default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-3 lane decoder with that ring size");
             }
 #undef LZ4HIP_LAUNCH_LANE3
-#undef LZ4HIP_LAUNCH_LANE3_POL
         }
+#endif
+        else return fail(LZ4HIP_E_ARGUMENT, "decoder_gen: this library has no lane decoder of that generation");
         count_dispatch(LZ4HIP_K_DECODE_LANE);
     }
     if (wave_filter >= 0) {
@@ -556,7 +634,7 @@ struct DeviceWorker {
                 cv.wait(lk, [&] { return has_job; });
                 j = std::move(job); has_job = false;
             }
-            j();
+            try { j(); } catch (...) {}                              // (jobs report through their own state; see run_host_batch_multi)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 finished = true;
@@ -594,29 +672,99 @@ DeviceWorker* device_worker(int logical)
     return g_worker[logical];
 }
 
-thread_local unsigned g_row_thread_share = 1;
+// ---- the row pool: gathers and scatters between caller memory and the pinned staging ------------------------------------
+// Plain memcpy of rows, ~10 GB/s per core -- and with six slices per batch the calling thread used to spend more time in them
+// than PCIe needs for the payload (round 3: 16 threads, started and joined per call: 24 GB/s for a 16 384-block decode).  Now
+// ONE persistent pool per process, started on first use: min(hardware threads / 4, 64) threads (knob host_threads), shared by
+// every caller -- the device workers of a multi-device call included: each of their jobs is cut into chunks that any pool
+// thread (and the submitting thread) may take, so eight devices share the pool instead of getting two threads each.
+struct RowJob {
+    std::function<void(int64_t)> f;
+    int64_t n = 0, chunk = 1;
+    std::atomic<int64_t> next{ 0 }, remaining{ 0 };
+    std::mutex m;
+    std::condition_variable done_cv;
+    // runs chunks until none is left; returns when this thread found the job exhausted
+    void work()
+    {
+        for (;;) {
+            const int64_t lo = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (lo >= n) return;
+            const int64_t hi = lo + chunk < n ? lo + chunk : n;
+            for (int64_t i = lo; i < hi; i++) f(i);
+            if (remaining.fetch_sub(hi - lo, std::memory_order_acq_rel) == hi - lo) {
+                std::lock_guard<std::mutex> lk(m);
+                done_cv.notify_all();
+            }
+        }
+    }
+};
+struct RowPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<RowJob>> q;
+    unsigned started = 0;
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<RowJob> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                j = q.front();
+            }
+            j->work();
+            std::lock_guard<std::mutex> lk(mu);
+            if (!q.empty() && q.front() == j) q.pop_front();          // exhausted: the next job's turn
+        }
+    }
+    unsigned want_threads()
+    {
+        if (knob(kKnobHostThreads) > 0) return (unsigned)knob(kKnobHostThreads);
+        unsigned t = std::thread::hardware_concurrency() / 4;
+        return t < 8 ? 8 : (t > 64 ? 64 : t);
+    }
+    // queues the job and returns at once; wait() (which also works on it) before anything it touches is reused
+    std::shared_ptr<RowJob> submit(int64_t n, std::function<void(int64_t)> f)
+    {
+        const unsigned want = want_threads();
+        auto j = std::make_shared<RowJob>();
+        j->f = std::move(f); j->n = n;
+        j->chunk = n / ((int64_t)want * 4) > 0 ? n / ((int64_t)want * 4) : 1;
+        j->remaining.store(n);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (started + 1 < want) {                              // (the submitting thread works too)
+                try { std::thread(&RowPool::loop, this).detach(); }
+                catch (const std::system_error&) { break; }           // no more threads to be had: fewer helpers, same result
+                started++;
+            }
+            q.push_back(j);
+        }
+        cv.notify_all();
+        return j;
+    }
+    void wait(const std::shared_ptr<RowJob>& j)
+    {
+        j->work();
+        std::unique_lock<std::mutex> lk(j->m);
+        j->done_cv.wait(lk, [&] { return j->remaining.load(std::memory_order_acquire) == 0; });
+    }
+    void run(int64_t n, std::function<void(int64_t)> f) { wait(submit(n, std::move(f))); }
+};
+RowPool* row_pool()
+{
+    static RowPool* p = new RowPool();                               // never destroyed: its threads outlive main()
+    return p;
+}
 
-// f(i) for i in [0, n): on the calling thread for small jobs, on up to 16 threads (LZ4HIP_HOST_THREADS) for large ones (row gathers and
-// scatters between caller memory and the pinned staging are plain memcpy, ~10 GB/s per core).
+// f(i) for i in [0, n): on the calling thread for small jobs, on the row pool for large ones.
 template <class F>
 void for_rows(int64_t n, size_t bytes, F f)
 {
-    unsigned t = std::thread::hardware_concurrency();
-    unsigned cap = knob(kKnobHostThreads) > 0 ? (unsigned)knob(kKnobHostThreads) : 16u;
-    cap = cap / g_row_thread_share;                                  // the device workers of a multi-device call share the budget
-    t = t > cap ? cap : t;
-    if (bytes < (8u << 20) || n < 2 || t < 2) { for (int64_t i = 0; i < n; i++) f(i); return; }
-    if ((int64_t)t > n) t = (unsigned)n;
-    std::vector<std::thread> pool;
-    int64_t started_to = 0;
-    for (unsigned k = 0; k < t; k++) {
-        const int64_t lo = n * k / t, hi = n * (k + 1) / t;
-        try { pool.emplace_back([=] { for (int64_t i = lo; i < hi; i++) f(i); }); }
-        catch (const std::system_error&) { break; }                  // no more threads to be had: the caller does the rest
-        started_to = hi;
-    }
-    for (int64_t i = started_to; i < n; i++) f(i);
-    for (auto& th : pool) th.join();
+    if (bytes < (4u << 20) || n < 2) { for (int64_t i = 0; i < n; i++) f(i); return; }
+    try { row_pool()->run(n, std::function<void(int64_t)>(f)); }
+    catch (const std::bad_alloc&) { for (int64_t i = 0; i < n; i++) f(i); }   // (idempotent copies: doing them again is harmless)
 }
 
 // Stage a host batch through device memory, run `run` on it, copy results (and dst payloads) back.
@@ -656,7 +804,12 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
     const int want_slices = knob(kKnobHostSlices) > 0 ? knob(kKnobHostSlices) : auto_slices;
     int64_t per_slice = (n + want_slices - 1) / want_slices;
     int64_t lo = (int64_t)((32u << 20) / row_bytes), hi = (int64_t)((512u << 20) / row_bytes);
-    if (slice_hint > 0 && knob(kKnobHostSlices) <= 0) { per_slice = slice_hint; hi = hi > slice_hint ? hi : slice_hint; }
+    if (slice_hint > 0 && knob(kKnobHostSlices) <= 0 && max_src <= 65536) {
+        // (the hint is for the LZ4HC kernels of blocks <= 64 KiB; whatever the rows are, a slice stays below 4 GiB of staging)
+        const int64_t cap4g = (int64_t)((4ull << 30) / row_bytes);
+        const int64_t hinted = slice_hint < (hi > cap4g ? hi : cap4g) ? slice_hint : (hi > cap4g ? hi : cap4g);
+        per_slice = hinted; hi = hi > hinted ? hi : hinted;
+    }
     per_slice = per_slice < lo ? lo : per_slice;
     per_slice = per_slice > hi ? hi : per_slice;
     per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
@@ -693,18 +846,29 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
     auto dst_cap = [&](int64_t i) { return hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all; };
 
     // drain slice [first, first + cnt) from pinned slot `slot` into the caller's buffers
+    // The scatter of a slice runs on the row pool WITHOUT the calling thread waiting for it: that thread goes on gathering
+    // the next slice (round 3 did gather k+1 and scatter k-1 one after the other: ~23 of the 34 ms of a 16 384-block decode).
+    // A slot's pinned buffer is reused only after its scatter has finished.
+    std::shared_ptr<RowJob> scatter_job[kHostSlots];
+    auto scatter_wait = [&](int slot) {
+        if (scatter_job[slot]) { row_pool()->wait(scatter_job[slot]); scatter_job[slot].reset(); }
+    };
     auto scatter = [&](int64_t first, int64_t cnt, int slot) {
         const uint8_t* po = (const uint8_t*)g_pin_out[slot].p;
         const int32_t* res = (const int32_t*)(po + out_res);
         for (int64_t j = 0; j < cnt; j++) hb->result[first + j] = res[j];
-        for_rows(cnt, (size_t)cnt * d_stride, [&, po, res, first](int64_t j) {
+        auto row = [=](int64_t j) {
             // bytes the caller gets back: the result for encoders / unknown-size decode, the full size for known-size decode
-            const int32_t cap = dst_cap(first + j);
+            const int32_t cap = hb->dst_cap ? hb->dst_cap[first + j] : hb->dst_cap_all;
             int64_t nbytes = dst_len_is_result ? res[j] : cap;
             if (!dst_len_is_result && res[j] < 0) nbytes = 0;
             if (nbytes > cap) nbytes = cap;
-            if (nbytes > 0) memcpy(dst_row(first + j), po + d_stride * (size_t)j, (size_t)nbytes);
-        });
+            uint8_t* to = (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[first + j] : (first + j) * hb->dst_stride);
+            if (nbytes > 0) memcpy(to, po + d_stride * (size_t)j, (size_t)nbytes);
+        };
+        if ((size_t)cnt * d_stride < (4u << 20) || cnt < 2) { for (int64_t j = 0; j < cnt; j++) row(j); return; }
+        try { scatter_job[slot] = row_pool()->submit(cnt, std::function<void(int64_t)>(row)); }
+        catch (const std::bad_alloc&) { for (int64_t j = 0; j < cnt; j++) row(j); }
     };
 #define PIPE_TRY(expr) do { if ((expr) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, #expr " failed"); } } while (0)
 
@@ -727,6 +891,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
         const int64_t cnt = n - first < per_slice ? n - first : per_slice;
         const int slot = (int)(slice % slots);
         while (!err && drained + slots <= slice) drain_one();        // the slot's previous slice must be out of its buffers
+        scatter_wait(slot);                                          // ... and in the caller's
         if (err) break;
         uint8_t* pi = (uint8_t*)g_pin_in[slot].p;
         int32_t* lens = (int32_t*)(pi + in_lens);
@@ -758,6 +923,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
         while (!err && drained < slice && hipEventQuery(pp.e_out[drained % slots]) == hipSuccess) drain_one();
     }
     while (!err && drained < slice) drain_one();
+    for (int k = 0; k < kHostSlots; k++) scatter_wait(k);           // (also on error: the jobs read this frame's buffers)
 #undef PIPE_TRY
     if (err) {
         (void)hipStreamSynchronize(pp.s_in); (void)hipStreamSynchronize(pp.s_out);
@@ -838,8 +1004,11 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
             post_rc = w->post([sh, phys, share, dst_len_is_result, run, slice_hint] {
                 if (sh->b.n_blocks == 0) return;
                 if (hipSetDevice(phys) != hipSuccess) { sh->rc = LZ4HIP_E_DEVICE; sh->err = "hipSetDevice failed"; return; }
-                g_row_thread_share = share;
-                sh->rc = run_host_batch(&sh->b, dst_len_is_result, run, slice_hint);
+                (void)share;
+                // nothing may be thrown across the worker's loop (a detached thread: std::terminate for the whole process)
+                try { sh->rc = run_host_batch(&sh->b, dst_len_is_result, run, slice_hint); }
+                catch (const std::bad_alloc&) { sh->rc = LZ4HIP_E_MEMORY; g_last_error = "out of host memory in a device worker"; }
+                catch (const std::exception& e) { sh->rc = LZ4HIP_E_DEVICE; g_last_error = std::string("device worker: ") + e.what(); }
                 if (sh->rc) sh->err = g_last_error;                  // thread-local: carry it back to the caller
             });
             if (post_rc) { w->busy.unlock(); break; }
@@ -946,7 +1115,13 @@ int lz4hip_release_workspaces(void)
         { std::lock_guard<std::mutex> lk(g_worker_mu); w = g_worker[k]; }
         if (!w) continue;
         std::lock_guard<std::mutex> own(w->busy);
-        if (w->post([dev] { if (hipSetDevice(dev) == hipSuccess) release_host_context(dev); })) continue;
+        // (a worker is indexed by its slot, not by a device: it may hold a context for every device it ever served)
+        if (w->post([] {
+                int nd = 0;
+                if (hipGetDeviceCount(&nd) != hipSuccess) return;
+                for (int d = 0; d < nd && d < 64; d++)
+                    if (host_context(d, false) && hipSetDevice(d) == hipSuccess) release_host_context(d);
+            })) continue;
         w->wait();
     }
     return 0;

@@ -29,6 +29,9 @@
 #ifndef LZ4HIP_ITERATION_HOOK
 #define LZ4HIP_ITERATION_HOOK(lane) ((void)0)
 #endif
+#ifndef LZ4HIP_STAT
+#define LZ4HIP_STAT(slot, cond) ((void)0)   /* the emulator build counts lane-iterations per state (tools/emu_decoder_stats.py) */
+#endif
 
 namespace lz4hip {
 
@@ -44,22 +47,25 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //   R      bytes of output ring per lane (multiple of 16)
 //   P      bytes of input per piece (32 or 64), loaded by the lane itself
 //   FU     flush unit: 64 (one line, four lanes) or 128 (two adjacent lines, eight lanes)
+//   FS     flush store instructions per iteration (1 or 2): each carries 64 / (FU / 16) units
 //   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
-template <bool KNOWN, int R, int P, int FU, int POL = 0>
+template <bool KNOWN, int R, int P, int FU, int FS, int POL = 0>
 LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
                                      uint8_t* dst, int oend)
 {
     static_assert(R >= 128 && R % 16 == 0 && R <= 1008, "ring: a multiple of 16 bytes, 128 .. 1008");
     static_assert(P == 32 || P == 64, "input piece: 32 or 64 bytes");
     static_assert(FU == 64 || (FU == 128 && R >= 192), "flush unit: 64 bytes, or 128 with a ring of at least 192");
+    static_assert(FS == 1 || FS == 2, "one or two flush store instructions per iteration");
     constexpr int RW = R / 4;                                        // ring rows (one dword per lane per row)
     constexpr bool RPOW2 = (RW & (RW - 1)) == 0;
     constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
     constexpr int NW = 4 + P / 4, NL = P / 16;                       // window dwords, loads per piece
     constexpr int HPR = FU / 16, RECS_PER_STORE = 64 / HPR;          // helper lanes per flush record, records per store instruction
-    constexpr int kFlushRecs = (LZ4HIP_DEC4_FLUSH_RECS) ? (LZ4HIP_DEC4_FLUSH_RECS) : 2 * RECS_PER_STORE;
+    constexpr int kFlushRecs = (LZ4HIP_DEC4_FLUSH_RECS) ? (LZ4HIP_DEC4_FLUSH_RECS) : FS * RECS_PER_STORE;
+    constexpr bool kLineNoWrap = R % 64 == 0;                        // a 64-byte line of the ring (16 rows from a multiple of 16) never wraps inside
     constexpr int kNearMax = R - 20;                                 // an append writes whole dwords, up to 19 bytes past its last byte
-    constexpr int kVm = 3 + NL;                                      // vector-memory instructions per iteration: two flush stores, far fetch, NL input loads
+    constexpr int kVm = FS + 1 + NL;                                 // vector-memory instructions per iteration: FS flush stores, far fetch, NL input loads
     Aligned16* const flush_rec = (Aligned16*)(lds + kRingBytes);
     const uint32_t lane4 = (uint32_t)lane << 2;
 
@@ -93,8 +99,9 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     uint32_t p_l0 = 0, p_l1 = 0, p_l2 = 0;
     int hdr = 0;                 // the cursor is at a sequence's offset field (its literals were streamed)
     uint32_t token = 0;
-    int final_seen = 0, final_run = 0, result = 0, done = 0, flush_blocked = 0;
+    int final_seen = 0, final_run = 0, result = 0, done = 0;
     if (!active || (!KNOWN && iend == 0)) { done = 1; final_seen = 1; }   // lz4.c:946 returns -(0)
+    const uint32_t out_limit = oend > kLastLiterals ? (uint32_t)(oend - kLastLiterals) : 0u;   // lz4.c:893 / :1024: a match may not end past oend - LASTLITERALS
     wv::u32x4 fa = { 0, 0, 0, 0 }, fb = { 0, 0, 0, 0 };
 #pragma unroll
     for (int j = 0; j < NW; j++) W[j] = 0;
@@ -149,7 +156,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         {
             const bool no_more = wb + 16 + P >= in_total;            // W holds the last piece of the source
             const bool cross = (d >= P) & ((lvalid != 0) | no_more);
-            const wv::mask_t cm = wv::cond(cross);
+            const wv::mask_t cm = wv::cond(d >= P) & (wv::cond(lvalid != 0) | wv::cond(no_more));   // (lane masks combined by scalar instructions)
 #pragma unroll
             for (int j = 0; j < 4; j++) W[j] = wv::sel(cm, W[P / 4 + j], W[j]);
 #pragma unroll
@@ -162,6 +169,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             lvalid = cross ? 0 : lvalid;
         }
         const bool staged16 = d < P;                                 // the 16 bytes at the cursor lie in W (what lies past the source is never used)
+        LZ4HIP_STAT(0, true); LZ4HIP_STAT(1, done == 0); LZ4HIP_STAT(2, (done == 0) & !staged16);
         uint32_t x0, x1, x2, x3;
         {
             // W[k .. k + 4], k = d / 4, through a binary tree of selects; then the byte rotation
@@ -195,7 +203,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             v0 = wv::perm(r1, r0, sr); v1 = wv::perm(r2, r1, sr); v2 = wv::perm(r3, r2, sr); v3 = wv::perm(r4, r3, sr);
         }
 
-        // ---- (T2) flush finished output, FU bytes at a time, FU / 16 lanes per unit: ALWAYS two store instructions ----
+        // ---- (T2) flush finished output, FU bytes at a time, FU / 16 lanes per unit: ALWAYS FS store instructions ----
         {
             const bool need = (done == 0) & (op - fl >= FU);
             const uint64_t needy = wv::ballot(need);
@@ -216,9 +224,10 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             }
             const int sub = lane % HPR;
 #pragma unroll
-            for (int base = 0; base < 2 * RECS_PER_STORE; base += RECS_PER_STORE) {
+            for (int base = 0; base < FS * RECS_PER_STORE; base += RECS_PER_STORE) {
                 const int idx = base + lane / HPR;
                 const bool act = idx < cnt;
+                const wv::mask_t act_m = wv::cond(idx < cnt);
                 uint64_t g = 0;
                 uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                 if (act) {
@@ -226,10 +235,12 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
                     g = ((uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32)) + (uint64_t)(r.w[1] + 16u * (uint32_t)sub);
                     // the owner's lane bits are in r.w[0]; this helper takes rows 4*sub .. 4*sub+3 of the unit
                     const uint32_t b0 = ring_add(r.w[0], 1024u * (uint32_t)sub);
-                    q0 = L4_RING(b0); q1 = L4_RING(ring_add(b0, 256u)); q2 = L4_RING(ring_add(b0, 512u)); q3 = L4_RING(ring_add(b0, 768u));
+                    if (kLineNoWrap) { q0 = L4_RING(b0); q1 = L4_RING(b0 + 256u); q2 = L4_RING(b0 + 512u); q3 = L4_RING(b0 + 768u); }   // (immediate offsets)
+                    else { q0 = L4_RING(b0); q1 = L4_RING(ring_add(b0, 256u)); q2 = L4_RING(ring_add(b0, 512u)); q3 = L4_RING(ring_add(b0, 768u)); }
                 }
-                wv::vm_store16_pred(act, g, q0, q1, q2, q3);
+                wv::vm_store16_mask(act_m, g, q0, q1, q2, q3);
             }
+            LZ4HIP_STAT(3, need); LZ4HIP_STAT(4, need & !mine);
             if (go) {
                 wv::mem_sync();                                      // records and ring rows are free to be overwritten again
                 fl += mine ? FU : 0;
@@ -242,11 +253,14 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         const int stride = (near & (off < 16)) ? off : 16;          // a near match whose source would overlap the chunk copies `off` bytes and doubles off
         int n = can ? (rem < stride ? rem : stride) : 0;
         n = ((kind == kK4Zero) & (n > 8)) ? 8 : n;
+        LZ4HIP_STAT(5, (done == 0) & (rem > 0)); LZ4HIP_STAT(6, (done == 0) & (rem > 0) & (n == 0)); LZ4HIP_STAT(7, (done == 0) & (rem > 0) & !room);
+        LZ4HIP_STAT(8, (done == 0) & (rem > 0) & (kind == kK4Far) & (gready == 0)); LZ4HIP_STAT(9, (done == 0) & (rem > n));
         const int rem_after = rem - n;
         const int op_end = op + rem;                                 // where the current copy ends = where the parsed-ahead sequence's literals go
 
         // ---- (T4) parse ahead: the next sequence's header (needs only the cursor) ----
         const bool may_parse = (pv == 0) & (final_seen == 0) & !(lit & (rem > 0)) & staged16;
+        LZ4HIP_STAT(10, may_parse); LZ4HIP_STAT(11, (done == 0) & (pv != 0));
         if (may_parse) {
             const uint32_t tok = hdr ? token : (x0 & 255u);
             const uint32_t t4 = tok >> 4, b1 = (x0 >> 8) & 255u, mlc = tok & 15u;
@@ -271,7 +285,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             // what the 16-byte view cannot decide goes to the byte-wise parser: the end of the source, length bytes of 255,
             // the final literal run (lz4.c:851 / :965), every error (lz4.c:863,893 / :980,1024)
             bool trap = (ip + 16 > iend) | (e1 & (b1 == 255u)) | (ip + 1 + (e1 ? 1 : 0) + ll > iend);
-            trap |= in_win & ((e2 & (extb == 255u)) | (vo > lit_end) | ((int64_t)lit_end + ml > (int64_t)oend - kLastLiterals));
+            trap |= in_win & ((e2 & (extb == 255u)) | (vo > lit_end) | ((uint32_t)lit_end + (uint32_t)ml > out_limit));   // (lit_end < 2^31 + 270, ml <= 274: no wrap)
             if (KNOWN) trap |= (hdr == 0) & (lit_end > oend - 8);
             else       trap |= ((hdr == 0) & ((lit_end > oend - kMfLimit) | (ip + 1 + (e1 ? 1 : 0) + ll > iend - 8))) | (in_win & e2 & !(p_after < iend - (kLastLiterals + 1)));
             p_l0 = wv::alignbyte(x1, x0, 1); p_l1 = wv::alignbyte(x2, x1, 1); p_l2 = wv::alignbyte(x3, x2, 1);
@@ -346,24 +360,26 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         // in this iteration (the source of the chunk appended at output position p is p - off; a lane that could not append
         // what it holds simply fetches the same bytes again)
         {
-            const bool f_cont = (kind == kK4Far) & (rem_after > 0);
-            const bool f_first = (rem_after == 0) & room & (pv != 0) & (p_ml != 0) & (p_flags == 0) & (p_off > kNearMax);
-            const int f_pos = f_cont ? op + n - off : op_end + p_ll - p_off;
-            const bool f_want = f_cont | f_first;
-            const bool f_do = f_want & (f_pos + 16 <= fl);
-            wv::vm_load16_pred<POL & 3>(f_do, (uint64_t)dst + (uint64_t)(uint32_t)f_pos, ldF);
-            flush_blocked = (f_want & !f_do) ? 1 : 0;
-            gready = f_do ? 1 : 0;                                   // (only read while kind == kK4Far)
+            // (the lane masks of the simple comparisons, combined by scalar instructions)
+            const wv::mask_t m_rem0 = wv::cond(rem_after == 0);
+            const wv::mask_t f_cont = wv::cond(kind == kK4Far) & ~m_rem0;
+            const wv::mask_t f_first = m_rem0 & wv::cond(op - fl <= R - 46) & wv::cond(pv != 0) & wv::cond(p_ml != 0) & wv::cond(p_flags == 0) & wv::cond(p_off > kNearMax);
+            const int f_pos = (int)wv::sel(f_cont, (uint32_t)(op + n - off), (uint32_t)(op_end + p_ll - p_off));
+            const wv::mask_t f_want = f_cont | f_first;
+            const wv::mask_t f_do = f_want & wv::cond(f_pos + 16 <= fl);
+            wv::vm_load16_mask<POL & 3>(f_do, (uint64_t)dst + (uint64_t)(uint32_t)f_pos, ldF);
+            gready = (int)wv::sel(f_do, 1u, 0u);                     // (only read while kind == kK4Far)
+            LZ4HIP_STAT(15, gready != 0); LZ4HIP_STAT(16, wv::sel(f_want & ~f_do, 1u, 0u) != 0u);
         }
 
         // ---- (T6) the next piece of input, once L is free: ALWAYS NL load instructions, each lane for itself ----
         {
             const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for
-            const bool req = (done == 0) & (lvalid == 0) & (us_pend == 0) & (lpos < in_total);
+            const wv::mask_t req = wv::cond((done | lvalid | us_pend) == 0) & wv::cond(lpos < in_total);
             const uint64_t g = src_al + (uint64_t)(uint32_t)lpos;
 #pragma unroll
-            for (int j = 0; j < NL; j++) wv::vm_load16_pred<(POL >> 2) & 3>(req, g + 16u * (unsigned)j, L[j]);
-            ld_pend = req ? 1 : 0;
+            for (int j = 0; j < NL; j++) wv::vm_load16_mask<(POL >> 2) & 3>(req, g + 16u * (unsigned)j, L[j]);
+            ld_pend = (int)wv::sel(req, 1u, 0u);
         }
 
         // ================================ BOTTOM ================================
@@ -394,6 +410,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         // ---- (B4) promote the parsed-ahead sequence: its inline literals, then its copy becomes the current one ----
         {
             const bool promote = (rem == 0) & (pv != 0) & room;
+            LZ4HIP_STAT(12, promote); LZ4HIP_STAT(13, (done == 0) & (rem == 0) & (pv != 0) & !room); LZ4HIP_STAT(14, (done == 0) & (rem == 0) & (pv == 0));
             const bool perr = promote & ((p_flags & kF4Err) != 0);
             const bool pgo = promote & !perr;
             L4_APPEND(p_l0, p_l1, p_l2, 0u, pgo ? p_ll : 0, false);
@@ -435,7 +452,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
-template <bool KNOWN, int R, int P, int FU, int POL = 0>
+template <bool KNOWN, int R, int P, int FU, int FS, int POL = 0>
 __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
 {
     LZ4HIP_STATIC_LDS(lds, lane4_lds_bytes(R));
@@ -450,7 +467,7 @@ __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
     if (!wv::any(active)) return;
     const uint8_t* src = active ? batch_src(b, blk) : nullptr;
     uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
-    const int r = lane4_decode_block<KNOWN, R, P, FU, POL>(lds, lane, active, src, src_len, dst, out_size);
+    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, POL>(lds, lane, active, src, src_len, dst, out_size);
     if (active) b.result[blk] = r;
 }
 

@@ -19,7 +19,8 @@
 
 namespace lz4hip {
 
-constexpr int kLaneEncodeWavesPerCu = 24;     // 16: 44.8, 24: 49.5, 32: 48.2 GB/s on D2 (profiles/r03/encoder_and_hc_residency_ab.txt)
+constexpr int kLaneEncodeWavesPerCu = 16;     // twelve fresh processes (profiles/r04/encoder_reproducibility.txt): 16 -> 53.8 / 54.0 / 54.3 GB/s on D2, 24 -> 44.0 / 53.3 / 53.3
+                                              // (round 3's 24 came from a same-process A/B: the rate is bimodal, 44-46 or 53-54, with where the slab lands)
 constexpr int kLaneTableBytes = 32768;      // per lane: tagged u32[8192] (64k variant) or u32[4096] (generic variant)
 
 // The hash table of one block as this mapping keeps it.  What the algorithm sees is exactly the reference's table

@@ -24,9 +24,12 @@
 #include "lz4hip_common.hpp"
 #include "lz4hip_encode_lane.hpp"   // lane_copy, lane_put_length
 #include "lz4hip_hc.hpp"            // hash15
-#include "lz4hip_hc_lane.hpp"       // slab sizes
 
 namespace lz4hip {
+
+constexpr int kHcLaneWavesPerCu = 16;   // one block takes a lane ~2 s of dependent memory round trips: throughput = lanes in flight (4: 1.8, 8: 3.0, 16: 4.8, 20: 4.8 GB/s)
+constexpr size_t kHcLaneSlab16 = 65536 + 131072;    // u16 heads + u16 chain
+constexpr size_t kHcLaneSlab32 = 131072 + 131072;   // u32 heads + u16 chain
 
 #ifndef LZ4HIP_HC_CTRL_EVERY
 #define LZ4HIP_HC_CTRL_EVERY 8      /* 2 / 4 / 8 / 16: 7.9 / 8.1 / 8.3 / 8.3 GB/s on D2 (profiles/r03/hc_convergent_control_batching_interval.txt) */

@@ -161,13 +161,43 @@ LZ4HIP_DEVICE void vm_wait_list(u32x4& a, u32x4 (&l)[M])
 // window it keeps in registers.  Written in plain C++ the compiler recognises a dynamically indexed array and moves the array
 // to scratch memory (measured: 4 000 cycles per lookup, tools/microbench_select_tree.hip); v_cndmask_b32 through inline
 // assembly keeps it in registers (4.5 cycles per select).  cond() turns the per-lane condition into the lane mask once.
-typedef uint64_t mask_t;
-LZ4HIP_DEVICE mask_t cond(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// A lane mask is a value of its own (an SGPR pair): masks of SIMPLE comparisons combine with scalar instructions.  (Handing
+// a compound condition to a ballot makes the compiler materialise the bool in a VGPR and compare it again: two vector
+// instructions per ballot.)
+struct mask_t { uint64_t v; };
+LZ4HIP_DEVICE mask_t cond(bool p) { return mask_t{ __builtin_amdgcn_ballot_w64(p) }; }
+LZ4HIP_DEVICE mask_t operator&(mask_t a, mask_t b) { return mask_t{ a.v & b.v }; }
+LZ4HIP_DEVICE mask_t operator|(mask_t a, mask_t b) { return mask_t{ a.v | b.v }; }
+LZ4HIP_DEVICE mask_t operator~(mask_t a) { return mask_t{ ~a.v }; }
+LZ4HIP_DEVICE bool any(mask_t m) { return m.v != 0ull; }
 LZ4HIP_DEVICE uint32_t sel(mask_t m, uint32_t a, uint32_t b)      // m ? a : b
 {
     uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m.v));
     return r;
+}
+// vm_load16_pred / vm_store16_pred with the lane mask given
+template <int POLICY = 0>
+LZ4HIP_DEVICE void vm_load16_mask(mask_t mk, uint64_t addr, u32x4& v)
+{
+    const uint64_t m = mk.v;
+    uint64_t saved;
+#define LZ4HIP_VM_LOAD(MODS)                                                                                                      \
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off" MODS "\n\ts_mov_b64 exec, %[sv]"       \
+                 : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m) : "memory")
+    if (POLICY == 1) LZ4HIP_VM_LOAD(" nt");
+    else if (POLICY == 2) LZ4HIP_VM_LOAD(" sc1");
+    else if (POLICY == 3) LZ4HIP_VM_LOAD(" sc0 sc1");
+    else LZ4HIP_VM_LOAD("");
+#undef LZ4HIP_VM_LOAD
+}
+LZ4HIP_DEVICE void vm_store16_mask(mask_t mk, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint64_t m = mk.v;
+    uint64_t saved;
+    const u32x4 v = { a, b, c, d };
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_store_dwordx4 %[a], %[d], off\n\ts_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved) : [a] "v"(addr), [d] "v"(v), [m] "s"(m) : "memory");
 }
 
 // DS_MSKOR_B32: MEM = (MEM & ~mask) | data -- a byte-granular merge into an aligned LDS dword without reading it back.

@@ -5,6 +5,8 @@
 
 static unsigned long long g_iterations = 0;   // loop iterations of the lane decoders (all wavefronts), counted by lane 0
 #define LZ4HIP_ITERATION_HOOK(lane) do { if ((lane) == 0) g_iterations++; } while (0)
+static unsigned long long g_stat[32];         // lane-iterations per state of the fourth-generation lane decoder (tools/emu_decoder_stats.py)
+#define LZ4HIP_STAT(slot, cond) do { if (cond) g_stat[slot]++; } while (0)
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
@@ -19,6 +21,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #include "lz4hip_hc_lane.hpp"
 #include "lz4hip_hc_conv.hpp"
 #include "lz4hip_hc_nat.hpp"
+#include "lz4hip_hc_nat_lane.hpp"
 #include "lz4hip_hc_lcp.hpp"
 #endif
 
@@ -91,19 +94,14 @@ void emu_decode_lane4(int known, const uint8_t* src, int64_t src_stride, const i
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
-#define EMU_LANE4(R, P, FU)                                                                                                     \
-    do {                                                                                                                        \
-        if (known) simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<true, R, P, FU>(b, filter); });         \
-        else       simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<false, R, P, FU>(b, filter); });        \
-    } while (0)
+#define EMU_LANE4(CFG)                                                                                                          \
+    case CFG: {                                                                                                                 \
+        constexpr int R = (CFG) % 1000, P = ((CFG) / 1000 & 2) ? 32 : 64, FU = ((CFG) / 1000 & 1) ? 128 : 64, FS = ((CFG) / 1000 & 4) ? 1 : 2;  \
+        if (known) simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<true, R, P, FU, FS>(b, filter); });     \
+        else       simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<false, R, P, FU, FS>(b, filter); });    \
+    } break
     switch (cfg) {
-    case 128: EMU_LANE4(128, 64, 64); break;
-    case 2128: EMU_LANE4(128, 32, 64); break;
-    case 192: EMU_LANE4(192, 64, 64); break;
-    case 1192: EMU_LANE4(192, 64, 128); break;
-    case 3192: EMU_LANE4(192, 32, 128); break;
-    case 1256: EMU_LANE4(256, 64, 128); break;
-    case 2240: EMU_LANE4(240, 32, 64); break;
+    EMU_LANE4(128); EMU_LANE4(2128); EMU_LANE4(192); EMU_LANE4(1192); EMU_LANE4(3192); EMU_LANE4(7192); EMU_LANE4(1256); EMU_LANE4(2240); EMU_LANE4(5256);
     default: simt::die("emu_decode_lane4: configuration not instantiated", cfg, 0);
     }
 #undef EMU_LANE4
@@ -273,5 +271,6 @@ unsigned long long emu_compare(const uint8_t* x, int64_t xs, const uint8_t* y, i
 }
 
 unsigned long long emu_steps() { return simt::rt().steps; }
+void emu_stats(unsigned long long* out, int reset) { for (int i = 0; i < 32; i++) { out[i] = g_stat[i]; if (reset) g_stat[i] = 0; } }
 unsigned long long emu_iterations(int reset) { const unsigned long long v = g_iterations; if (reset) g_iterations = 0; return v; }
 }

@@ -155,9 +155,16 @@ inline void vm_wait(u32x4&, u32x4&)
 }
 template <int N, int M>
 inline void vm_wait_list(u32x4& a, u32x4 (&l)[M]) { u32x4 dummy{}; vm_wait<N>(a, dummy); }
-typedef bool mask_t;
-inline mask_t cond(bool p) { return p; }
-inline uint32_t sel(mask_t m, uint32_t a, uint32_t b) { return m ? a : b; }
+struct mask_t { bool v; };
+inline mask_t cond(bool p) { return mask_t{ p }; }
+inline mask_t operator&(mask_t a, mask_t b) { return mask_t{ a.v && b.v }; }
+inline mask_t operator|(mask_t a, mask_t b) { return mask_t{ a.v || b.v }; }
+inline mask_t operator~(mask_t a) { return mask_t{ !a.v }; }
+inline bool any(mask_t m) { return any(m.v); }
+inline uint32_t sel(mask_t m, uint32_t a, uint32_t b) { return m.v ? a : b; }
+template <int POLICY = 0>
+inline void vm_load16_mask(mask_t m, uint64_t addr, u32x4& v) { vm_load16_pred<POLICY>(m.v, addr, v); }
+inline void vm_store16_mask(mask_t m, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { vm_store16_pred(m.v, addr, a, b, c, d); }
 inline void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data) { *p = (*p & ~mask) | data; }
 
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }

@@ -503,6 +503,84 @@ def test_multi_device_threaded_path_does_not_leak(gpu, oracle):
     _lib.check(_lib.lib().lz4hip_release_workspaces())
 
 
+def test_multi_device_eight_logical_devices_16384_blocks(gpu, oracle):
+    """BASELINE configs[4] shape in miniature, through the C ABI's own sharding (lz4hip_*_batch_host_multi): 16 384 blocks of
+    64 KiB round-robin over EIGHT device workers ("logical_devices" = 8 over whatever devices the box has).  Every result in
+    global block order, sampled payloads against the oracle, the whole batch round-trips; the wall-clock rates are printed
+    (on a one-GPU box they are a code-path check -- eight workers share one device -- not a scaling measurement)."""
+    import ctypes as C
+    import time
+    import torch
+    from lz4net_amd import _lib, batch
+    n = 16384
+    raw_h = batch.synth(2, 515, 0, n).cpu().numpy()
+    comp_h = np.zeros((n, batch.BOUND_STRIDE), np.uint8)
+    lens = np.full(n, batch.BLOCK, np.int32)
+    caps = np.full(n, batch.BOUND, np.int32)
+    clen = np.zeros(n, np.int32)
+    eb = _lib.Batch(src=raw_h.ctypes.data, src_off=None, src_stride=raw_h.strides[0], src_len=lens.ctypes.data,
+                    dst=comp_h.ctypes.data, dst_off=None, dst_stride=comp_h.strides[0], dst_cap=caps.ctypes.data,
+                    dst_cap_all=0, src_len_all=0, result=clen.ctypes.data, n_blocks=n)
+    back_h = np.zeros_like(raw_h)
+    res = np.zeros(n, np.int32)
+    db = _lib.Batch(src=comp_h.ctypes.data, src_off=None, src_stride=comp_h.strides[0], src_len=clen.ctypes.data,
+                    dst=back_h.ctypes.data, dst_off=None, dst_stride=back_h.strides[0], dst_cap=lens.ctypes.data,
+                    dst_cap_all=0, src_len_all=0, result=res.ctypes.data, n_blocks=n)
+    with _lib.tuning(logical_devices=8):
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().lz4hip_encode_batch_host_multi(C.byref(eb), 0, C.c_uint64(0)))
+        t1 = time.perf_counter()
+        _lib.check(_lib.lib().lz4hip_decode_batch_host_multi(C.byref(db), 1, C.c_uint64(0)))
+        t2 = time.perf_counter()
+    assert (clen > 0).all() and (res == clen).all()
+    assert np.array_equal(back_h, raw_h)
+    for i in list(range(0, n, 1021)) + [n - 1]:
+        w = oracle.compress(raw_h[i])
+        assert clen[i] == len(w) and np.array_equal(comp_h[i, :len(w)], w), i
+    print(f"8 logical devices over {torch.cuda.device_count()} physical, {n} blocks: encode {n * 65536 / (t1 - t0) / 1e9:.2f} GB/s, "
+          f"decode {n * 65536 / (t2 - t1) / 1e9:.2f} GB/s wall clock (first call of the workers, staging allocation included)")
+    _lib.check(_lib.lib().lz4hip_release_workspaces())
+
+
+def test_hc_host_batch_blocks_over_64k(gpu, oracle):
+    """LZ4HC through the host-pointer entry point with blocks above 64 KiB (32-bit heads, the kernels with the insert loop):
+    the slice size of the staging pipeline is bounded in BYTES whatever the rows are (the 16384-block slice hint
+    of the LZ4HC path was applied to rows of any size).  40 blocks of 70 000 .. 600 000 bytes; every block against the oracle."""
+    rng = np.random.default_rng(77)
+    blocks = []
+    for i in range(40):
+        sz = int(rng.choice([70000, 65537, 131072, 200000, 600000]))
+        blocks.append(oracle.gen(2 if i % 2 else 3, 71, i * 16, (sz + 65535) // 65536).reshape(-1)[:sz].copy())
+    res, dst = gpu.encode(blocks, hc=True)
+    for i, a in enumerate(blocks):
+        w = oracle.compress(a, hc=True)
+        assert res[i] == len(w), (i, a.size, res[i], len(w))
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+
+
+def test_hc_sub_chunks_identical(gpu, oracle):
+    """The pipelined LZ4HC lane launch (sub-chunks whose table builders and lane kernels overlap on separate streams) must
+    produce the bytes of the one-after-the-other launch: 8192 blocks, 1 / 2 / 3 sub-chunks, sampled blocks against the oracle."""
+    import torch
+    from lz4net_amd import _lib, batch
+    n = 8192
+    raw = batch.synth(2, 808, 0, n)
+    host = raw.cpu().numpy()
+    outs = []
+    for subs in (1, 2, 3):
+        comp = torch.full((n, batch.BOUND_STRIDE), 0xA5, dtype=torch.uint8, device="cuda")
+        with ForcedMapping("LZ4HIP_HC", "lane"), _lib.tuning(hc_sub_chunks=subs):
+            clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)
+            torch.cuda.synchronize()
+        outs.append((clen.cpu().numpy(), batch.checksum(comp, clen).cpu().numpy()))
+        lens = outs[-1][0]
+        for i in (0, 1, n // 2 - 1, n // 2, n - 1):
+            w = oracle.compress(host[i], hc=True)
+            assert lens[i] == len(w) and np.array_equal(comp[i, :len(w)].cpu().numpy(), w), (subs, i)
+    for k in (1, 2):
+        assert np.array_equal(outs[0][0], outs[k][0]) and np.array_equal(outs[0][1], outs[k][1]), k
+
+
 def test_hc_lane_slab_reuse(gpu, oracle):
     """LZ4HC lane kernel with ONE wavefront in the grid ("hc_groups" = 1): its 64 lanes encode 320 blocks, five each on
     average, on slabs that are never re-initialised beyond the heads and chain[0] -- blocks of 64 KiB, 70 000 bytes

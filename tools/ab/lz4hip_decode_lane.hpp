@@ -1,3 +1,5 @@
+// (NOT part of the product library: the second generation of the lane decoder, superseded by lz4net_amd/csrc/lz4hip_decode_lane4.hpp;
+//  kept under tools/ab/ for A/B runs -- libraries built with -DLZ4HIP_TUNING_BUILD -- and emulator tests)
 // lz4hip_decode_lane.hpp -- lane-per-block LZ4 decoder: 64 blocks per wavefront, every byte of global traffic moved by
 // wave-cooperative accesses, and exactly one vector-memory wait per loop iteration, for loads issued a full
 // iteration earlier.

@@ -1,3 +1,5 @@
+// (NOT part of the product library: the third generation of the lane decoder, superseded by lz4net_amd/csrc/lz4hip_decode_lane4.hpp;
+//  kept under tools/ab/ for A/B runs -- libraries built with -DLZ4HIP_TUNING_BUILD -- and emulator tests)
 // lz4hip_decode_lane3.hpp -- lane-per-block LZ4 decoder, third generation: the same mapping and the same LDS rings as
 // lz4hip_decode_lane.hpp (64 blocks per wavefront, input staged through a per-lane ring, output appended to a per-lane
 // ring and flushed in 64-byte lines by four lanes per line), rebuilt around what the round-2 counters said

@@ -1,3 +1,4 @@
+// (NOT part of the product library: round 2's LZ4HC lane kernel, kept under tools/ab/ for A/B runs and emulator tests)
 // lz4hip_hc_lane.hpp -- batched LZ4HC block encoder for gfx950, one LANE per block, bit-exact to
 // the reference (same functions as lz4hip_hc.hpp: LZ4_compressHCCtx and its match finder,
 // original/lz4hc.c:330-755 == src/LZ4pn/LZ4Codec.Unsafe64HC.Dirty.cs:72-523).
@@ -12,12 +13,16 @@
 #include "lz4hip_common.hpp"
 #include "lz4hip_encode_lane.hpp"   // lane_count_equal, lane_copy, lane_put_length
 #include "lz4hip_hc.hpp"            // hash15
+#include "lz4hip_hc_conv.hpp"       // slab sizes
 
 namespace lz4hip {
 
+// (kHcLaneWavesPerCu, kHcLaneSlab16 / 32: lz4hip_hc_conv.hpp, which the product keeps)
+#if 0
 constexpr int kHcLaneWavesPerCu = 16;   // one block takes a lane ~2 s of dependent memory round trips: throughput = lanes in flight (4: 1.8, 8: 3.0, 16: 4.8, 20: 4.8 GB/s)
 constexpr size_t kHcLaneSlab16 = 65536 + 131072;    // u16 heads + u16 chain
 constexpr size_t kHcLaneSlab32 = 131072 + 131072;   // u32 heads + u16 chain
+#endif
 
 template <class HeadT>
 struct LaneHc {

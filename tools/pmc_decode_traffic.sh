@@ -15,7 +15,7 @@ import csv, glob, json, sys, collections
 out, dist, blocks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 vals = collections.defaultdict(list)
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
-    lane = lambda r: 'decode_lane3_kernel' in r['Kernel_Name'] or 'decode_lane_kernel' in r['Kernel_Name']
+    lane = lambda r: 'decode_lane4_kernel' in r['Kernel_Name'] or 'decode_lane3_kernel' in r['Kernel_Name'] or 'decode_lane_kernel' in r['Kernel_Name']
     rows = [r for r in csv.DictReader(open(f)) if lane(r) or 'decode_kernel' in r['Kernel_Name']]
     big = max(int(r['Grid_Size']) for r in rows if lane(r))
     per = collections.defaultdict(float); n = collections.Counter()

@@ -19,7 +19,7 @@ sys.path.insert(0, '.')
 import bench
 out, dist, blocks, hcb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 # per kernel family: the dispatches with the largest grid are the full-size launches; average their counters
-fam = {"decode": ("decode_lane3_kernel", "decode_lane_kernel", "decode_kernel"), "encode_fast": ("encode_fast_lane_kernel", "encode_fast_kernel"), "encode_hc": ("hc_nat_chain_kernel", "hc_lcp_fill_kernel", "encode_hc_lcp_kernel", "encode_hc_nat_kernel", "encode_hc_conv_kernel", "encode_hc_lane_kernel")}
+fam = {"decode": ("decode_lane4_kernel", "decode_lane3_kernel", "decode_lane_kernel", "decode_kernel"), "encode_fast": ("encode_fast_lane_kernel", "encode_fast_kernel"), "encode_hc": ("hc_nat_chain_kernel", "hc_lcp_fill_kernel", "encode_hc_lcp_kernel", "encode_hc_nat_kernel", "encode_hc_conv_kernel", "encode_hc_lane_kernel")}
 vals = {k: collections.defaultdict(list) for k in fam}
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     rows = list(csv.DictReader(open(f)))
