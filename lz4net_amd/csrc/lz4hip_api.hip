@@ -85,7 +85,7 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeGeneration = 4;
-constexpr int kLane4Config = 7192;           // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units, one flush store instruction per iteration
+constexpr int kLane4Config = 11192;          // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units, two flush store instructions in every second iteration
 constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
@@ -490,19 +490,20 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         const int gen = knob(kKnobDecoderGen) ? knob(kKnobDecoderGen) : kLaneDecodeGeneration;
         if (gen == 4) {
             // decoder_ring = ring bytes + 1000 x variant (variant bit 0: 128-byte flush units, bit 1: 32-byte input pieces,
-            // bit 2: one flush store instruction per iteration)
+            // bit 2: one flush store instruction per iteration, bit 3: the flush runs in every second iteration only,
+            // bit 4: input pieces are requested in the other iterations only)
             const int cfg = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane4Config;
-#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS)                                                                             \
+#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS, FE, IE)                                                                         \
             do {                                                                                                                \
-                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
-                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS, FE, IE>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS, FE, IE>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
             } while (0)
-#define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2); break
+#define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2, ((CFG) / 1000 & 8) ? 2 : 1, ((CFG) / 1000 & 16) ? 2 : 1); break
             switch (cfg) {
             LZ4HIP_LANE4_CASE(kLane4Config);
 #ifdef LZ4HIP_TUNING_BUILD                                              /* residency / ring / piece / flush-unit sweeps (tools/ab_decoder_knobs.py) */
             LZ4HIP_LANE4_CASE(128); LZ4HIP_LANE4_CASE(2128); LZ4HIP_LANE4_CASE(6128); LZ4HIP_LANE4_CASE(3192); LZ4HIP_LANE4_CASE(192); LZ4HIP_LANE4_CASE(1192); LZ4HIP_LANE4_CASE(2192);
-            LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
+            LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(7192); LZ4HIP_LANE4_CASE(27192); LZ4HIP_LANE4_CASE(25192); LZ4HIP_LANE4_CASE(11256); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
 #endif
             default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
             }
@@ -684,25 +685,25 @@ struct RowJob {
     std::atomic<int64_t> next{ 0 }, remaining{ 0 };
     std::mutex m;
     std::condition_variable done_cv;
-    // runs chunks until none is left; returns when this thread found the job exhausted
-    void work()
+    bool exhausted() const { return next.load(std::memory_order_relaxed) >= n; }
+    // runs one chunk; false when none was left
+    bool work_one()
     {
-        for (;;) {
-            const int64_t lo = next.fetch_add(chunk, std::memory_order_relaxed);
-            if (lo >= n) return;
-            const int64_t hi = lo + chunk < n ? lo + chunk : n;
-            for (int64_t i = lo; i < hi; i++) f(i);
-            if (remaining.fetch_sub(hi - lo, std::memory_order_acq_rel) == hi - lo) {
-                std::lock_guard<std::mutex> lk(m);
-                done_cv.notify_all();
-            }
+        const int64_t lo = next.fetch_add(chunk, std::memory_order_relaxed);
+        if (lo >= n) return false;
+        const int64_t hi = lo + chunk < n ? lo + chunk : n;
+        for (int64_t i = lo; i < hi; i++) f(i);
+        if (remaining.fetch_sub(hi - lo, std::memory_order_acq_rel) == hi - lo) {
+            std::lock_guard<std::mutex> lk(m);
+            done_cv.notify_all();
         }
+        return true;
     }
 };
 struct RowPool {
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::shared_ptr<RowJob>> q;
+    std::deque<std::shared_ptr<RowJob>> q;                            // in priority order: gathers (they feed the pipeline) before scatters
     unsigned started = 0;
     void loop()
     {
@@ -710,12 +711,14 @@ struct RowPool {
             std::shared_ptr<RowJob> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !q.empty(); });
-                j = q.front();
+                for (;;) {
+                    while (!q.empty() && q.front()->exhausted()) q.pop_front();
+                    for (auto& c : q) if (!c->exhausted()) { j = c; break; }
+                    if (j) break;
+                    cv.wait(lk);
+                }
             }
-            j->work();
-            std::lock_guard<std::mutex> lk(mu);
-            if (!q.empty() && q.front() == j) q.pop_front();          // exhausted: the next job's turn
+            j->work_one();                                            // one chunk, then look again: a more urgent job may have arrived
         }
     }
     unsigned want_threads()
@@ -725,7 +728,7 @@ struct RowPool {
         return t < 8 ? 8 : (t > 64 ? 64 : t);
     }
     // queues the job and returns at once; wait() (which also works on it) before anything it touches is reused
-    std::shared_ptr<RowJob> submit(int64_t n, std::function<void(int64_t)> f)
+    std::shared_ptr<RowJob> submit(int64_t n, std::function<void(int64_t)> f, bool urgent)
     {
         const unsigned want = want_threads();
         auto j = std::make_shared<RowJob>();
@@ -739,18 +742,18 @@ struct RowPool {
                 catch (const std::system_error&) { break; }           // no more threads to be had: fewer helpers, same result
                 started++;
             }
-            q.push_back(j);
+            if (urgent) q.push_front(j); else q.push_back(j);
         }
         cv.notify_all();
         return j;
     }
     void wait(const std::shared_ptr<RowJob>& j)
     {
-        j->work();
+        while (j->work_one()) {}
         std::unique_lock<std::mutex> lk(j->m);
         j->done_cv.wait(lk, [&] { return j->remaining.load(std::memory_order_acquire) == 0; });
     }
-    void run(int64_t n, std::function<void(int64_t)> f) { wait(submit(n, std::move(f))); }
+    void run(int64_t n, std::function<void(int64_t)> f) { wait(submit(n, std::move(f), true)); }
 };
 RowPool* row_pool()
 {
@@ -867,7 +870,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
             if (nbytes > 0) memcpy(to, po + d_stride * (size_t)j, (size_t)nbytes);
         };
         if ((size_t)cnt * d_stride < (4u << 20) || cnt < 2) { for (int64_t j = 0; j < cnt; j++) row(j); return; }
-        try { scatter_job[slot] = row_pool()->submit(cnt, std::function<void(int64_t)>(row)); }
+        try { scatter_job[slot] = row_pool()->submit(cnt, std::function<void(int64_t)>(row), false); }
         catch (const std::bad_alloc&) { for (int64_t j = 0; j < cnt; j++) row(j); }
     };
 #define PIPE_TRY(expr) do { if ((expr) != hipSuccess) { err = fail(LZ4HIP_E_DEVICE, #expr " failed"); } } while (0)

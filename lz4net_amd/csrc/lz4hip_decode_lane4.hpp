@@ -25,6 +25,7 @@
 // LZ4_uncompress_unknownOutputSize, original/lz4.c:916-1044).
 #pragma once
 #include "lz4hip_common.hpp"
+#include <type_traits>
 
 #ifndef LZ4HIP_ITERATION_HOOK
 #define LZ4HIP_ITERATION_HOOK(lane) ((void)0)
@@ -47,9 +48,11 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //   R      bytes of output ring per lane (multiple of 16)
 //   P      bytes of input per piece (32 or 64), loaded by the lane itself
 //   FU     flush unit: 64 (one line, four lanes) or 128 (two adjacent lines, eight lanes)
-//   FS     flush store instructions per iteration (1 or 2): each carries 64 / (FU / 16) units
+//   FS     flush store instructions per flushing iteration (1 or 2): each carries 64 / (FU / 16) units
+//   FE     the flush runs in every FE-th iteration (1 or 2)
+//   IE     2: the next input piece is only requested in the iterations that do not flush (needs FE == 2); 1: in every iteration
 //   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
-template <bool KNOWN, int R, int P, int FU, int FS, int POL = 0>
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
 LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
                                      uint8_t* dst, int oend)
 {
@@ -57,6 +60,8 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     static_assert(P == 32 || P == 64, "input piece: 32 or 64 bytes");
     static_assert(FU == 64 || (FU == 128 && R >= 192), "flush unit: 64 bytes, or 128 with a ring of at least 192");
     static_assert(FS == 1 || FS == 2, "one or two flush store instructions per iteration");
+    static_assert(FE == 1 || FE == 2, "the flush runs in every iteration or in every second one");
+    static_assert(IE == 1 || (IE == 2 && FE == 2), "input requests in every iteration, or alternating with the flush");
     constexpr int RW = R / 4;                                        // ring rows (one dword per lane per row)
     constexpr bool RPOW2 = (RW & (RW - 1)) == 0;
     constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
@@ -65,7 +70,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     constexpr int kFlushRecs = (LZ4HIP_DEC4_FLUSH_RECS) ? (LZ4HIP_DEC4_FLUSH_RECS) : FS * RECS_PER_STORE;
     constexpr bool kLineNoWrap = R % 64 == 0;                        // a 64-byte line of the ring (16 rows from a multiple of 16) never wraps inside
     constexpr int kNearMax = R - 20;                                 // an append writes whole dwords, up to 19 bytes past its last byte
-    constexpr int kVm = FS + 1 + NL;                                 // vector-memory instructions per iteration: FS flush stores, far fetch, NL input loads
+    // vector-memory instructions per iteration: FS flush stores (if it flushes), far fetch, NL input loads (if it requests input)
     Aligned16* const flush_rec = (Aligned16*)(lds + kRingBytes);
     const uint32_t lane4 = (uint32_t)lane << 2;
 
@@ -147,7 +152,10 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 
     // One iteration.  ldF: the far-match registers loaded in THIS iteration; usF: those loaded in the previous one (consumed
     // at the bottom of this one).  ld_pend / us_pend: this lane requested its next piece in this / the previous iteration.
-    auto iteration = [&](wv::u32x4& ldF, wv::u32x4& usF, int& ld_pend, int& us_pend) __attribute__((always_inline)) -> bool {
+    auto iteration = [&](auto flush_tag, wv::u32x4& ldF, wv::u32x4& usF, int& ld_pend, int& us_pend) __attribute__((always_inline)) -> bool {
+        constexpr bool FLUSH = decltype(flush_tag)::value;           // (with FE == 2 only every second iteration flushes)
+        constexpr bool INPUT = IE == 1 || !FLUSH;
+        constexpr int kVm = (FLUSH ? FS : 0) + 1 + (INPUT ? NL : 0);
         LZ4HIP_ITERATION_HOOK(lane);
         // ================================ TOP ================================
         // ---- (T1) the input window: take the next piece in once the cursor has left the current one; the 16 bytes at the
@@ -204,7 +212,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         }
 
         // ---- (T2) flush finished output, FU bytes at a time, FU / 16 lanes per unit: ALWAYS FS store instructions ----
-        {
+        if constexpr (FLUSH) {
             const bool need = (done == 0) & (op - fl >= FU);
             const uint64_t needy = wv::ballot(need);
             const int cnt_all = wv::popc64(needy);
@@ -373,13 +381,15 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         }
 
         // ---- (T6) the next piece of input, once L is free: ALWAYS NL load instructions, each lane for itself ----
-        {
+        if constexpr (INPUT) {
             const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for
             const wv::mask_t req = wv::cond((done | lvalid | us_pend) == 0) & wv::cond(lpos < in_total);
             const uint64_t g = src_al + (uint64_t)(uint32_t)lpos;
 #pragma unroll
             for (int j = 0; j < NL; j++) wv::vm_load16_mask<(POL >> 2) & 3>(req, g + 16u * (unsigned)j, L[j]);
             ld_pend = (int)wv::sel(req, 1u, 0u);
+        } else {
+            ld_pend = 0;
         }
 
         // ================================ BOTTOM ================================
@@ -442,8 +452,8 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     };
 
     for (;;) {
-        if (iteration(fa, fb, pend_a, pend_b)) break;
-        if (iteration(fb, fa, pend_b, pend_a)) break;
+        if (iteration(std::true_type{}, fa, fb, pend_a, pend_b)) break;
+        if (iteration(std::integral_constant<bool, FE == 1>{}, fb, fa, pend_b, pend_a)) break;
     }
     return result;
 #undef L4_RING
@@ -452,7 +462,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
-template <bool KNOWN, int R, int P, int FU, int FS, int POL = 0>
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
 __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
 {
     LZ4HIP_STATIC_LDS(lds, lane4_lds_bytes(R));
@@ -467,7 +477,7 @@ __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
     if (!wv::any(active)) return;
     const uint8_t* src = active ? batch_src(b, blk) : nullptr;
     uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
-    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, POL>(lds, lane, active, src, src_len, dst, out_size);
+    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL>(lds, lane, active, src, src_len, dst, out_size);
     if (active) b.result[blk] = r;
 }
 

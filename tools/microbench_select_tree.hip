@@ -19,6 +19,26 @@ __device__ __forceinline__ uint32_t sel(uint64_t m, uint32_t a, uint32_t b)
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
+// four selects under one condition as VOP2 (implicit VCC): is the e32 form cheaper than the e64 form with an SGPR-pair mask?
+__device__ __forceinline__ void sel4_vcc(uint64_t m, uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1,
+                                         uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3)
+{
+    asm("s_mov_b64 vcc, %[m]\n\tv_cndmask_b32_e32 %[r0], %[b0], %[a0], vcc\n\tv_cndmask_b32_e32 %[r1], %[b1], %[a1], vcc\n\tv_cndmask_b32_e32 %[r2], %[b2], %[a2], vcc\n\tv_cndmask_b32_e32 %[r3], %[b3], %[a3], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+        : [m] "s"(m), [a0] "v"(a0), [b0] "v"(b0), [a1] "v"(a1), [b1] "v"(b1), [a2] "v"(a2), [b2] "v"(b2), [a3] "v"(a3), [b3] "v"(b3) : "vcc");
+}
+__device__ __forceinline__ void view_tree12_vcc(const uint32_t (&w)[20], uint32_t k, uint32_t (&v)[5])
+{
+    const uint64_t c2 = __builtin_amdgcn_ballot_w64((k & 4u) != 0), c1 = __builtin_amdgcn_ballot_w64((k & 2u) != 0), c0 = __builtin_amdgcn_ballot_w64((k & 1u) != 0);
+    uint32_t b[8], c[8], d[8];
+    sel4_vcc(c2, b[0], b[1], b[2], b[3], w[4], w[0], w[5], w[1], w[6], w[2], w[7], w[3]);
+    sel4_vcc(c2, b[4], b[5], b[6], b[7], w[8], w[4], w[9], w[5], w[10], w[6], w[11], w[7]);
+    sel4_vcc(c1, c[0], c[1], c[2], c[3], b[2], b[0], b[3], b[1], b[4], b[2], b[5], b[3]);
+    sel4_vcc(c1, c[4], c[5], c[6], c[7], b[6], b[4], b[7], b[5], b[7], b[6], b[7], b[7]);
+    sel4_vcc(c0, d[0], d[1], d[2], d[3], c[1], c[0], c[2], c[1], c[3], c[2], c[4], c[3]);
+    sel4_vcc(c0, d[4], d[5], d[6], d[7], c[5], c[4], c[5], c[5], c[5], c[5], c[5], c[5]);
+    for (int i = 0; i < 5; i++) v[i] = d[i];
+}
 __device__ __forceinline__ void view_tree20(const uint32_t (&w)[20], uint32_t k, uint32_t (&v)[5])
 {
     const uint64_t c3 = __builtin_amdgcn_ballot_w64((k & 8u) != 0), c2 = __builtin_amdgcn_ballot_w64((k & 4u) != 0), c1 = __builtin_amdgcn_ballot_w64((k & 2u) != 0), c0 = __builtin_amdgcn_ballot_w64((k & 1u) != 0);
@@ -78,6 +98,10 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, const uint32_t* in, int i
             }
             d = cross ? d - 32 : d;
             view_tree12(w, d >> 2, v);
+        } else if (KIND == 6) {
+            const bool cross = d >= 32;
+            d = cross ? d - 32 : d;
+            view_tree12_vcc(w, d >> 2, v);
         } else if (KIND == 5) {
             d &= 63;
             const uint32_t row = d >> 2;
@@ -126,5 +150,6 @@ int main()
     run<3>("tree over 20 dwords + window switch (20 moves)", d, in, cus, base);
     run<4>("tree over 12 dwords + window switch (12 moves)", d, in, cus, base);
     run<5>("LDS rows (5 ds_read_b32)", d, in, cus, base);
+    run<6>("tree over 12 dwords as VOP2 + VCC (24 selects)", d, in, cus, base);
     return 0;
 }
