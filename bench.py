@@ -586,7 +586,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if wave_mapped
-                       else "lz4hip::decode_lane4_kernel<true,192,32,128,1,0> (one lane per block: input window in registers, 192-byte LDS output ring, 128-byte flush units, hand-counted vmcnt)"),
+                       else "lz4hip::decode_lane4_kernel<true,192,32,128,2,2,2,0> (one lane per block: input window in registers, 192-byte LDS output ring, 128-byte flush units, hand-counted vmcnt)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

@@ -85,7 +85,8 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeGeneration = 4;
-constexpr int kLane4Config = 11192;          // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units, two flush store instructions in every second iteration
+constexpr int kLane4Config = 27192;          // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units; iterations alternate between
+                                              // flushing (two store instructions) and requesting input (two load instructions)
 constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
@@ -503,7 +504,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             LZ4HIP_LANE4_CASE(kLane4Config);
 #ifdef LZ4HIP_TUNING_BUILD                                              /* residency / ring / piece / flush-unit sweeps (tools/ab_decoder_knobs.py) */
             LZ4HIP_LANE4_CASE(128); LZ4HIP_LANE4_CASE(2128); LZ4HIP_LANE4_CASE(6128); LZ4HIP_LANE4_CASE(3192); LZ4HIP_LANE4_CASE(192); LZ4HIP_LANE4_CASE(1192); LZ4HIP_LANE4_CASE(2192);
-            LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(7192); LZ4HIP_LANE4_CASE(27192); LZ4HIP_LANE4_CASE(25192); LZ4HIP_LANE4_CASE(11256); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
+            LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(7192); LZ4HIP_LANE4_CASE(11192); LZ4HIP_LANE4_CASE(25192); LZ4HIP_LANE4_CASE(11256); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
 #endif
             default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
             }

@@ -32,6 +32,13 @@
 #pragma once
 #include "lz4hip_common.hpp"
 
+#ifndef LZ4HIP_STAT
+#define LZ4HIP_STAT(slot, cond) ((void)0)   /* the emulator build counts (tools/emu_decoder_stats.py) */
+#endif
+#ifndef LZ4HIP_STAT_ADD
+#define LZ4HIP_STAT_ADD(slot, n) ((void)0)
+#endif
+
 namespace lz4hip {
 
 // 512-byte sliding register window over the compressed stream of one block.
@@ -130,6 +137,8 @@ LZ4HIP_DEVICE void wave_match_copy(uint8_t* dst, int pos, int off, int n)
 }
 
 constexpr int kWaveRingBytes = 4096;     // LDS mirror of a wavefront's most recent output (power of two)
+constexpr int kWaveBurstRecBytes = 1024; // ... followed by the burst's sequence records (64 x 16 bytes)
+constexpr int kWaveLdsBytes = kWaveRingBytes + kWaveBurstRecBytes;
 
 template <bool KNOWN>
 LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, int out_size, unsigned char* ring)
@@ -143,12 +152,103 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
     SrcWindow win;
     win.init(src, src_len);
 
+    // A BURST: a run of short sequences in one step (round 4).  The two paths below handle one sequence per trip of this loop,
+    // ~100 wave-instructions and ~940 cycles of dependent latency each -- which is what a batch too small for the lane mapping
+    // pays per sequence (a 64 KiB block of fuzzer-style data: 2.6 ms).  Here every lane parses the bytes at ip + lane AS IF a
+    // sequence started there (token, <= 6 literals, offset, match length in the token: 78 % / 88 % of the sequences of such data
+    // with <= 2 / <= 6 literals); a scalar walk from lane 0 follows the real sequence starts until 64 bytes of output are
+    // accounted for; then lane j produces output byte j of the burst: a literal out of its sequence's token lane, or a match
+    // byte from the LDS mirror of the recent output, or -- when its source lies inside the burst itself -- from the lane that
+    // produces that byte, in as many rounds as the dependencies are deep (the reference's byte-wise overlap semantics
+    // included: a match that overlaps itself is just a chain of such dependencies).  Anything the burst does not cover (length
+    // bytes, long runs, sources behind the mirror, the end of the block, every error) leaves the burst to the paths below,
+    // which remain the definition of the semantics.
+    const int o_burst = oend - 96, i_burst = iend - 112;
+    int burst_skip = 0, burst_fail = 0;                              // sequences to leave to the other paths after a burst that did not come about
+
     const int lane8 = (lane < 3 ? lane : 3) * 8;
     // While op <= o_safe and ip <= i_safe a sequence of at most 2 literals and a match of at most 18 bytes can neither be
     // the last one (lz4.c:851 / :965) nor run into the end of the output (:893 / :1024) nor read past the source.
     const int o_safe = KNOWN ? oend - 28 : oend - 32;
     const int i_safe = KNOWN ? iend - 5 : iend - 11;
     for (;;) {
+        if (burst_skip > 0) burst_skip--;
+        else if (op <= o_burst && ip <= i_burst) {
+            win.need(ip, 96);
+            const int idx0 = ip - win.base, J0 = idx0 >> 2, ph = idx0 & 3;
+            // D: lane i (< 32) holds the window's dword J0 + i;  then this lane's twelve bytes at ip + lane
+            const int di = J0 + (lane & 31);
+            const uint32_t Da = wv::shuffle(win.w0, di & 63), Db = wv::shuffle(win.w1, di & 63);
+            const uint32_t D = (di & 64) ? Db : Da;
+            const int bi = ph + lane, dj = bi >> 2;
+            const uint32_t x0 = wv::shuffle(D, dj), x1 = wv::shuffle(D, dj + 1), x2 = wv::shuffle(D, dj + 2);
+            const uint32_t sh = (uint32_t)bi & 3u;
+            const uint32_t v0 = wv::alignbyte(x1, x0, sh), v1 = wv::alignbyte(x2, x1, sh), v2 = x2 >> (8u * sh);
+            const uint32_t tok = v0 & 255u, ll = tok >> 4, mlc = tok & 15u;
+            const uint64_t rest8 = ((((uint64_t)v1 << 32) | v0) >> 8) | ((uint64_t)(v2 & 255u) << 56);   // the eight bytes after the token
+            const uint32_t off = (uint32_t)(rest8 >> (8u * (ll > 6u ? 0u : ll))) & 0xFFFFu;
+            const bool simple = (ll <= 6u) & (mlc != 15u) & (off != 0u);
+            const uint32_t olen = ll + mlc + (uint32_t)kMinMatch;
+            const uint32_t packed = olen | ((3u + ll) << 8);          // output bytes | input bytes of the sequence
+            // the real sequence starts, from lane 0 on: a wave-uniform walk, one v_readlane per sequence
+            const uint64_t simple_m = wv::ballot(simple);
+            int s_tok = 0, tot = 0;
+            uint64_t tok_m = 0, bound_m = 0;                         // token lanes of the burst; bit b: a sequence's output starts at byte b
+            bool hit_other = false;                                  // the walk ended at a sequence the burst does not cover
+            while (s_tok < 64) {
+                if (!((simple_m >> s_tok) & 1ull)) { hit_other = true; break; }
+                const uint32_t pk = wv::readlane(packed, s_tok);
+                const int ol = (int)(pk & 255u);
+                if (tot + ol > 64) break;
+                tok_m |= 1ull << s_tok; bound_m |= 1ull << tot;
+                tot += ol; s_tok += (int)(pk >> 8);
+            }
+            bool burst_done = false;
+            if (tok_m != 0ull) {
+                // token lanes leave a record per sequence in LDS (slot = its rank); output lane j reads the record of ITS sequence
+                const bool is_tok = (tok_m >> lane) & 1ull;
+                const uint32_t mine = is_tok ? olen : 0u;
+                const uint32_t ost = wv::scan_add(mine) - mine;      // where this token's sequence starts in the burst's output
+                Aligned16* const rec = (Aligned16*)(ring + kWaveRingBytes);
+                if (is_tok) rec[wv::rank_below(tok_m)] = Aligned16{ { ll | (off << 8), (uint32_t)rest8, (uint32_t)(rest8 >> 32), ost } };
+                wv::mem_sync();
+                const bool live = lane < tot;
+                const int k = wv::rank_below(bound_m) + (int)((bound_m >> lane) & 1ull) - 1;   // the sequence of output byte `lane`
+                const Aligned16 r = rec[live ? k : 0];
+                const int t_ll = (int)(r.w[0] & 255u), t_off = (int)(r.w[0] >> 8);
+                const int rel = lane - (int)r.w[3];
+                const bool is_lit = rel < t_ll;
+                const uint32_t litb = (uint32_t)((((uint64_t)r.w[2] << 32) | r.w[1]) >> (8 * (is_lit ? rel : 0))) & 255u;
+                const int srel = lane - t_off;                       // a match byte's source, relative to the burst's first byte
+                const bool hist = live & !is_lit & (srel < 0);
+                const int habs = op + srel;
+                const int ring_lo = op - kWaveRingBytes > ring_from ? op - kWaveRingBytes : ring_from;
+                if (!wv::any(hist & ((habs < ring_lo) | (habs < 0)))) {          // (a source before the block is an error: lz4.c:863 / :980, general path)
+                    uint32_t val = litb;
+                    bool res = is_lit | !live;
+                    if (hist) { val = ring[habs & (kWaveRingBytes - 1)]; res = true; }
+                    // sources inside the burst: pull from the lane that produces the byte, until nothing is left
+                    int rounds = 0;
+                    while (wv::any(!res)) {
+                        rounds++;
+                        const uint32_t sv = wv::shuffle(val, srel & 63), sr = wv::shuffle(res ? 1u : 0u, srel & 63);
+                        if (!res && sr != 0u) { val = sv; res = true; }
+                    }
+                    if (live) { dst[op + lane] = (uint8_t)val; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)val; }
+                    wv::mem_sync();
+                    LZ4HIP_STAT(20, lane == 0); LZ4HIP_STAT_ADD(21, lane == 0 ? wv::popc64(tok_m) : 0); LZ4HIP_STAT_ADD(22, lane == 0 ? rounds : 0);
+                    ip += s_tok; op += tot;
+                    burst_done = true;
+                    burst_fail = 0;
+                    if (hit_other) burst_skip = 1;                   // the next sequence is known to need the general path
+                }
+            }
+            if (burst_done) continue;
+            LZ4HIP_STAT(23, lane == 0);
+            burst_fail = burst_fail < 5 ? burst_fail + 1 : 5;       // no run of short sequences here: back off, 1, 2, 4 .. 32 sequences
+            burst_skip = 1 << burst_fail >> 1;
+            if (burst_skip < 1) burst_skip = 1;
+        }
         // ---- the common short sequence in one step: at most two literals and a match whose length is in the token (4..18),
         //      whose source neither overlaps the match itself nor this sequence's literals.  Token, literals and offset are
         //      the five bytes at ip: one look at the register window, no length bytes, one byte-per-lane gather and store.
@@ -178,12 +278,14 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                         if (lane < tll + t_ml) { dst[op + lane] = (uint8_t)v; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)v; }
                     }
                     wv::mem_sync();
+                    LZ4HIP_STAT(24, lane == 0);
                     ip += 3 + tll; op = t_lit_end + t_ml;
                     continue;
                 }
             }
         }
         // ---- token + literal length: lz4.c:843-844 / :953-961 ----
+        LZ4HIP_STAT(25, lane == 0);
         const uint32_t token = win.peek(ip); ip++;
         int ll = (int)(token >> 4);
         if (ll == 15) {
@@ -266,7 +368,7 @@ constexpr int kWaveDecodeWavesPerGroup = 4;
 template <bool KNOWN>
 __global__ void __launch_bounds__(64 * kWaveDecodeWavesPerGroup) decode_kernel(Batch b, int filter)
 {
-    LZ4HIP_STATIC_LDS(rings, kWaveDecodeWavesPerGroup * kWaveRingBytes);
+    LZ4HIP_STATIC_LDS(rings, kWaveDecodeWavesPerGroup * kWaveLdsBytes);
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv::wave_in_block();
     if (blk >= b.n_blocks) return;
     const int src_len = wv::uniform(batch_src_len(b, blk));
@@ -274,7 +376,7 @@ __global__ void __launch_bounds__(64 * kWaveDecodeWavesPerGroup) decode_kernel(B
     if (!block_selected(filter, src_len, out_size)) return;
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);
-    const int r = decode_block<KNOWN>(src, src_len, dst, out_size, rings + wv::wave_in_block() * kWaveRingBytes);
+    const int r = decode_block<KNOWN>(src, src_len, dst, out_size, rings + wv::wave_in_block() * kWaveLdsBytes);
     if (wv::lane() == 0) b.result[blk] = r;
 }
 

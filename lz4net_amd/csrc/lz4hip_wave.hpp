@@ -43,6 +43,33 @@ LZ4HIP_DEVICE uint64_t first_lane(uint64_t v) { return uniform(v); }
 // v_readlane_b32 with a wave-uniform lane index: result lands in an SGPR.
 LZ4HIP_DEVICE uint32_t readlane(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane); }
 
+// v_writelane_b32 with a wave-uniform value and a wave-uniform lane index: lane `dst_lane` of the result holds `value`, every
+// other lane keeps `old`.
+LZ4HIP_DEVICE uint32_t writelane(uint32_t old, uint32_t value, int dst_lane)
+{
+    // (inline assembly: this compiler has no writelane builtin.  gfx9 allows ONE scalar register per vector instruction, so the
+    //  lane select travels in M0; the s_nop covers the wait states a lane select needs after its register was written, which the
+    //  compiler cannot see into; readfirstlane pins both operands to scalar registers)
+    const uint32_t sv = (uint32_t)__builtin_amdgcn_readfirstlane((int)value);
+    const int sl = __builtin_amdgcn_readfirstlane(dst_lane);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
+    return old;
+}
+
+// Inclusive prefix sum over the 64 lanes (all lanes active): five DPP row shifts / broadcasts, no LDS, no scalar round trip.
+LZ4HIP_DEVICE uint32_t scan_add(uint32_t x)
+{
+#define LZ4HIP_DPP_ADD(CTRL, ROWS) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, false)
+    LZ4HIP_DPP_ADD(0x111, 0xF);      // row_shr:1
+    LZ4HIP_DPP_ADD(0x112, 0xF);      // row_shr:2
+    LZ4HIP_DPP_ADD(0x114, 0xF);      // row_shr:4
+    LZ4HIP_DPP_ADD(0x118, 0xF);      // row_shr:8
+    LZ4HIP_DPP_ADD(0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+    LZ4HIP_DPP_ADD(0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+#undef LZ4HIP_DPP_ADD
+    return x;
+}
+
 // Arbitrary cross-lane gather (ds_bpermute_b32): lane i receives v from lane idx_i.
 LZ4HIP_DEVICE uint32_t shuffle(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 

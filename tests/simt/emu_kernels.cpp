@@ -7,6 +7,7 @@ static unsigned long long g_iterations = 0;   // loop iterations of the lane dec
 #define LZ4HIP_ITERATION_HOOK(lane) do { if ((lane) == 0) g_iterations++; } while (0)
 static unsigned long long g_stat[32];         // lane-iterations per state of the fourth-generation lane decoder (tools/emu_decoder_stats.py)
 #define LZ4HIP_STAT(slot, cond) do { if (cond) g_stat[slot]++; } while (0)
+#define LZ4HIP_STAT_ADD(slot, n) do { g_stat[slot] += (unsigned long long)(n); } while (0)
 
 #include "lz4hip_common.hpp"
 #include "lz4hip_decode.hpp"
@@ -46,7 +47,7 @@ void emu_decode(int known, const uint8_t* src, int64_t src_stride, const int32_t
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
     const unsigned wpg = (unsigned)waves_per_group;
     dim3 grid((unsigned)((n + wpg - 1) / wpg)), block(64 * wpg);
-    const size_t lds = (size_t)wpg * kWaveRingBytes;
+    const size_t lds = (size_t)wpg * kWaveLdsBytes;
     if (known) simt::launch(grid, block, lds, [=] { decode_kernel<true>(b, filter); });
     else       simt::launch(grid, block, lds, [=] { decode_kernel<false>(b, filter); });
 }

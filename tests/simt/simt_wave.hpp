@@ -57,6 +57,27 @@ inline uint32_t readlane(uint32_t v, int src_lane)
     return (uint32_t)w[src_lane].slot[p];
 }
 
+inline uint32_t scan_add(uint32_t x)
+{
+    unsigned p, tag;
+    const simt::Lane* w = simt::exchange(x, 125, &p, &tag);
+    const int n = simt::wave_width(simt::rt().cur), me = lane();
+    uint32_t sum = 0;
+    for (int i = 0; i < n && i <= me; i++) {
+        if (!simt::took_part(w[i], p, tag)) simt::die("wv::scan_add() with inactive lanes (the DPP scan needs all 64)", i);
+        sum += (uint32_t)w[i].slot[p];
+    }
+    return sum;
+}
+
+inline uint32_t writelane(uint32_t old, uint32_t value, int dst_lane)
+{
+    // value and lane index are SGPR operands on hardware: both must be wave-uniform
+    if (uniform64(((uint64_t)(uint32_t)dst_lane << 32) | value, 115) != ((((uint64_t)(uint32_t)dst_lane) << 32) | value)) simt::die("wv::writelane() with non-uniform operands", dst_lane);
+    if (dst_lane < 0 || dst_lane >= 64) simt::die("wv::writelane() lane out of range", dst_lane);
+    return lane() == dst_lane ? value : old;
+}
+
 inline uint32_t shuffle(uint32_t v, int src_lane)
 {
     unsigned p, tag;

@@ -418,13 +418,13 @@ def test_lane_decoder_starved_flush(oracle, gen):
             comps = [oracle.compress(a) for a in blocks]
             for known in (True, False):
                 res, dst = emu.decode([np.concatenate([c, np.zeros(64, np.uint8)]) for c in comps], [a.size for a in blocks], known=known,
-                                      src_lens=None if known else [len(c) for c in comps], lane=11192 if gen == 4 else 128, stage=64, gen=gen)
+                                      src_lens=None if known else [len(c) for c in comps], lane=27192 if gen == 4 else 128, stage=64, gen=gen)
                 for i, (a, c) in enumerate(zip(blocks, comps)):
                     assert res[i] == (len(c) if known else a.size), (known, i, res[i])
                     assert np.array_equal(dst[i, :a.size], a), (known, i)
         # the odd-but-legal and malformed streams and the error-code matrix, in the same starved state
-        test_decode_arbitrary_streams(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c11192"}[gen])
-        test_decode_error_codes_match_oracle(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c11192"}[gen])
+        test_decode_arbitrary_streams(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c27192"}[gen])
+        test_decode_error_codes_match_oracle(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c27192"}[gen])
 
 
 @pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)

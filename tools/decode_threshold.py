@@ -1,4 +1,4 @@
-"""Decode rate of the wavefront mapping vs the lane mapping (generation 2 / 3) for small and mid-size batches (where is the crossover?).
+"""Decode rate of the wavefront mapping vs the lane mapping (default generation) for small and mid-size batches (where is the crossover?).
 usage: python tools/decode_threshold.py [dists] [sizes]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ for dist in dists:
     back = torch.empty_like(raw)
     for n in sizes:
         row = []
-        for name, gen in (("wave", 0), ("lane", 2), ("lane", 3)):
+        for name, gen in (("wave", 0), ("lane", 0)):
             _lib.tuning_set("decoder", name)
             _lib.tuning_set("decoder_gen", gen)
             batch.decode(comp[:n], clen[:n], back[:n], batch.BLOCK)
