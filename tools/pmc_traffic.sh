@@ -2,17 +2,19 @@
 # HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes as the MI355X guide prescribes) of the
 # three timed kernels of the default bench workload: decode (2^20 blocks), fast encode (2^20), LZ4HC (2^18).
 # Writes gpurun_out/pmc_traffic/pmc_traffic.json keyed on the hash of lz4net_amd/csrc (bench.py only quotes it when
-# the hash matches); copy it to profiles/r03/ to commit it.
+# the hash matches); copy it to profiles/r04/ to commit it.  PMC_REPARSE=1: only re-evaluate the CSVs already there.
 # Usage: bash tools/pmc_traffic.sh [dist] [blocks] [hc_blocks]
 dist=${1:-2}; blocks=${2:-1048576}; hcb=${3:-262144}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+if [ -z "$PMC_REPARSE" ]; then
 rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 360 rocprofv3 --pmc $pmc -d $out/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu --hc-only --blocks $blocks --hc-blocks $hcb --dist $dist > $out/bench_$i.json 2>> $out/err.txt
 done
-cd $GRAFT_REPO_ROOT
+fi
+cd ${GRAFT_REPO_ROOT:-.}
 python - $out $dist $blocks $hcb <<'PY'
 import csv, glob, json, sys, collections
 sys.path.insert(0, '.')
@@ -30,11 +32,13 @@ for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
         by_name = collections.defaultdict(list)
         for r in mine:
             by_name[(r['Kernel_Name'], r['Counter_Name'])].append(r)
+        # the bench command runs every full-size operation exactly TWICE (decode: --steps 2; fast encode: best of two; LZ4HC: two passes), and
+        # one operation may launch an instantiation more than once (LZ4HC: once per sub-chunk): per operation = sum over the full-size launches / 2
         per_counter = collections.defaultdict(float)
         for (name, counter), rs in by_name.items():
             big = max(int(r['Grid_Size']) for r in rs)
             full = [float(r['Counter_Value']) for r in rs if int(r['Grid_Size']) == big]
-            per_counter[counter] += sum(full) / len(full)
+            per_counter[counter] += sum(full) / 2.0
         for c, v in per_counter.items():
             vals[k][c].append(v)
 res = {"csrc_sha": bench.csrc_sha(), "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; bytes_per_launch = (FETCH + WRITE) * 1024, mean over the full-size launches; the guide's gfx950 caveat applies (FETCH_SIZE under-counts wide coalesced streaming reads by 2x; scattered widths uncalibrated)"}
@@ -43,7 +47,7 @@ for k in fam:
     if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
         fe = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']); wr = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])
         res[k] = {"dist": dist, "blocks": hcb if k == "encode_hc" else blocks, "fetch_bytes": int(fe * 1024), "write_bytes": int(wr * 1024),
-                  "bytes_per_launch": int((fe + wr) * 1024), "launches_averaged": len(v['FETCH_SIZE'])}
+                  "bytes_per_launch": int((fe + wr) * 1024), "operations_averaged": 2}
 json.dump(res, open(out + '/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res))
 PY
