@@ -133,6 +133,10 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 loop nest per lane; precomputed chains without lengths) exist only in -DLZ4HIP_TUNING_BUILD libraries
  *   "hc_ctrl_every", "hc_ctrl_lanes" [LZ4HIP_HC_CTRL_EVERY, LZ4HIP_HC_CTRL_LANES]  generation 4: the parse's control flow runs for all
  *                                 waiting lanes every N-th iteration (a power of two) or as soon as M lanes wait (0 = defaults 8 / 32)
+ *   "decoder_persist"            [LZ4HIP_DECODER_PERSIST]  lane decoder: 0 = automatic (one block per lane under hardware dispatch for large batches whose
+ *                                 blocks nearly all take the lane mapping; a persistent grid whose lanes pull blocks from a counter for batches of fewer
+ *                                 than three residency rounds and for batches with many blocks routed to the wavefront mapping -- counted on the device),
+ *                                 1 = always the persistent grid, 2 = never
  *   "hc_sub_chunks"              [LZ4HIP_HC_SUB_CHUNKS]  LZ4HC lane mapping, blocks <= 64 KiB: a chunk of blocks is cut into this many sub-chunks whose
  *                                 table builders and lane kernels overlap on separate streams (0 = default 2, 1 = one after the other, at most 8)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the

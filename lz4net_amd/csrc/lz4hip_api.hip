@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -63,6 +63,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "hc_gen", "LZ4HIP_HC_GEN", false },                           // LZ4HC lane mapping: 0 default; 4 lz4hip_hc_lcp.hpp (blocks <= 64 KiB), 2 lz4hip_hc_conv.hpp (larger blocks; <= 64 KiB in tuning builds); 1 lz4hip_hc_lane.hpp and 3 lz4hip_hc_nat.hpp in tuning builds only
     { "hc_ctrl_every", "LZ4HIP_HC_CTRL_EVERY", false }, { "hc_ctrl_lanes", "LZ4HIP_HC_CTRL_LANES", false },   // lz4hip_hc_lcp.hpp: control-flow batching (0 default)
     { "hc_sub_chunks", "LZ4HIP_HC_SUB_CHUNKS", false },             // LZ4HC lane launch: sub-chunks whose table builders and lane kernels overlap (0 default = 2, 1 = one after the other, max 8)
+    { "decoder_persist", "LZ4HIP_DECODER_PERSIST", false },         // lane decoder, default configuration: 0 the device picks one block per lane or the persistent grid, 1 always persistent, 2 never
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -469,6 +470,24 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
     return 0;
 }
 
+// Work counters of the persistent lane decoder: a small per-device ring of 256-byte slots, one per launch in flight (a slot is
+// reused after 64 further launches on that device).
+int decoder_counter(int dev, hipStream_t stream, unsigned long long** out)
+{
+    static void* ring[64];
+    static std::atomic<unsigned> next[64];
+    static std::mutex mu;
+    if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ring[dev]) HIP_TRY(hipMalloc(&ring[dev], 64 * 256));
+    }
+    uint8_t* slot = (uint8_t*)ring[dev] + 256 * (size_t)(next[dev].fetch_add(1) & 63u);
+    HIP_TRY(hipMemsetAsync(slot, 0, 16, stream));                   // work counter + selected-block count
+    *out = (unsigned long long*)slot;
+    return 0;
+}
+
 int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
 {
     if (b->n_blocks == 0) return 0;
@@ -500,6 +519,51 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS, FE, IE>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
             } while (0)
 #define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2, ((CFG) / 1000 & 8) ? 2 : 1, ((CFG) / 1000 & 16) ? 2 : 1); break
+            // Default configuration: TWO forms of the same kernel.  One block per lane under hardware dispatch is the faster one for
+            // a large batch whose blocks all take the lane mapping (2^20 D2 blocks: 980 vs 952 GB/s); the persistent grid, whose lanes pull
+            // blocks from a counter and skip what the filter does not select, wins when a wavefront would idle otherwise -- a batch of
+            // more than one but fewer than three residency rounds (2^18 blocks: 865 -> 938 GB/s) or a batch with many blocks routed to the
+            // wavefront mapping (half zeros: 68 -> 44 ms).  Which one runs is decided ON THE DEVICE: a counting launch, then both kernels, each of which
+            // returns at once unless the count says it is its turn (profiles/r04/decoder_persistent_lanes_ab.txt).
+            // Knob decoder_persist: 0 automatic, 1 always the persistent form, 2 never.
+            const int persist = knob(kKnobDecoderPersist);
+            if (cfg == kLane4Config && persist != 2) {
+                constexpr int R_ = kLane4Config % 1000, P_ = (kLane4Config / 1000 & 2) ? 32 : 64, FU_ = (kLane4Config / 1000 & 1) ? 128 : 64,
+                              FS_ = (kLane4Config / 1000 & 4) ? 1 : 2, FE_ = (kLane4Config / 1000 & 8) ? 2 : 1, IE_ = (kLane4Config / 1000 & 16) ? 2 : 1;
+                int dev = 0, cus = 0;
+                HIP_TRY(hipGetDevice(&dev));
+                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                static std::atomic<int> per_cu_cached[64];
+                int per_cu = dev >= 0 && dev < 64 ? per_cu_cached[dev].load(std::memory_order_relaxed) : 0;
+                if (per_cu <= 0) {
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_>, 64, 0));
+                    if (per_cu <= 0) per_cu = 1;
+                    if (dev >= 0 && dev < 64) per_cu_cached[dev].store(per_cu, std::memory_order_relaxed);
+                }
+                const int64_t capacity = (int64_t)per_cu * cus;
+                // 0: one block per lane only; 1: persistent only; 2: counted, one of the two
+                // (a batch that fits the residency in one round gives every lane one block either way: nothing to refill, no counter needed)
+                int mode = persist == 1 ? 1 : ((int64_t)grid <= capacity ? 0 : ((int64_t)grid < 3 * capacity ? 1 : (lane_filter == kAllBlocks ? 0 : 2)));
+                unsigned long long* counter = nullptr;
+                if (mode != 0) { int rc = decoder_counter(dev, stream, &counter); if (rc) return rc; }
+                const unsigned* gate = mode == 2 ? (const unsigned*)(counter + 1) : nullptr;       // (the slot's second qword: the count)
+                const unsigned threshold = (unsigned)(d.n_blocks - d.n_blocks / 10);            // "nearly every block": 90 %
+                if (mode == 2) {
+                    const unsigned cg = (unsigned)((d.n_blocks + 255) / 256 < 4096 ? (d.n_blocks + 255) / 256 : 4096);
+                    hipLaunchKernelGGL(count_selected_kernel, dim3(cg), dim3(256), 0, stream, d, lane_filter, (unsigned*)(counter + 1));
+                    HIP_TRY(hipGetLastError());
+                }
+                if (mode != 1) {
+                    if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                    else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                    HIP_TRY(hipGetLastError());
+                }
+                if (mode != 0) {
+                    const unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
+                    if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                    else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                }
+            } else
             switch (cfg) {
             LZ4HIP_LANE4_CASE(kLane4Config);
 #ifdef LZ4HIP_TUNING_BUILD                                              /* residency / ring / piece / flush-unit sweeps (tools/ab_decoder_knobs.py) */

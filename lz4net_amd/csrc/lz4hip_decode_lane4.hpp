@@ -41,6 +41,13 @@ namespace lz4hip {
 #endif
 constexpr unsigned lane4_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + 16u * 32u; }
 
+// What a lane does when its block is finished.  NoNext: nothing (one block per lane, the wavefront ends when its last lane does).
+// A persistent kernel passes a functor that stores the finished block's result and hands the lane its next block.
+struct NoNext {
+    static constexpr bool kPersistent = false;
+    LZ4HIP_DEVICE bool operator()(int, const uint8_t*&, int&, uint8_t*&, int&) const { return false; }
+};
+
 enum L4Kind { kK4None = 0, kK4Near = 1, kK4Far = 2, kK4Lit = 3, kK4Zero = 4 };
 enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: final literal run / corrupt stream / no match yet (its header follows the literals)
 
@@ -52,9 +59,9 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //   FE     the flush runs in every FE-th iteration (1 or 2)
 //   IE     2: the next input piece is only requested in the iterations that do not flush (needs FE == 2); 1: in every iteration
 //   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
-template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
-LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* __restrict__ src, int iend,
-                                     uint8_t* dst, int oend)
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0, class NEXT = NoNext>
+LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* src, int iend,
+                                     uint8_t* dst, int oend, NEXT next = NEXT())
 {
     static_assert(R >= 128 && R % 16 == 0 && R <= 1008, "ring: a multiple of 16 bytes, 128 .. 1008");
     static_assert(P == 32 || P == 64, "input piece: 32 or 64 bytes");
@@ -85,9 +92,9 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 #define L4_PHASE_SEL(p_) wv::alignbyte(0x07060504u, 0x03020100u, (uint32_t)(p_) & 3u)
 
     // ---- per-lane state ----
-    const int skew = (int)((uint64_t)src & (uint64_t)(P - 1));
-    const uint64_t src_al = (uint64_t)src - (uint64_t)skew;
-    const int in_total = iend > 0 ? (int)(((int64_t)skew + iend + P - 1) & ~(int64_t)(P - 1)) : 0;
+    int skew = 0, in_total = 0;
+    uint64_t src_al = 0;
+    uint32_t out_limit = 0;      // lz4.c:893 / :1024: a match may not end past oend - LASTLITERALS
     int ip = 0;                  // input cursor (block coordinates): next token / next streamed literal / next header
     // input window: W holds the bytes [wb, wb + 16 + P) of the aligned stream (wb = -16 mod P), L the piece that follows
     uint32_t W[NW];
@@ -105,30 +112,28 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     int hdr = 0;                 // the cursor is at a sequence's offset field (its literals were streamed)
     uint32_t token = 0;
     int final_seen = 0, final_run = 0, result = 0, done = 0;
-    if (!active || (!KNOWN && iend == 0)) { done = 1; final_seen = 1; }   // lz4.c:946 returns -(0)
-    const uint32_t out_limit = oend > kLastLiterals ? (uint32_t)(oend - kLastLiterals) : 0u;   // lz4.c:893 / :1024: a match may not end past oend - LASTLITERALS
+    int exhausted = 0;           // (persistent kernels) this lane has no further block
     wv::u32x4 fa = { 0, 0, 0, 0 }, fb = { 0, 0, 0, 0 };
 #pragma unroll
     for (int j = 0; j < NW; j++) W[j] = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) L[j] = wv::u32x4{ 0, 0, 0, 0 };
-    // the first two pieces (aligned pieces that overlap the source: they never leave the pages the source lies in)
-    if (done == 0) {
-        if (in_total > 0) {
-#pragma unroll
-            for (int j = 0; j < NL; j++) wv::load_global16(src_al + 16u * (unsigned)j, W[4 + 4 * j], W[5 + 4 * j], W[6 + 4 * j], W[7 + 4 * j]);
-        }
-        if (in_total > P) {
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                uint32_t a, b, c, e;
-                wv::load_global16(src_al + (uint64_t)P + 16u * (unsigned)j, a, b, c, e);
-                L[j] = wv::u32x4{ a, b, c, e };
-            }
-            lvalid = 1;
-        }
-    }
-    wv::wait_vector_memory();
+    // (Re)start this lane on the block src / iend / dst / oend: every piece of per-block state.  The window starts EMPTY, one piece before the
+    // stream (wb = -16 - P): the first trips of the loop request piece 0 into L, take it into W and request piece 1 like every later
+    // piece -- no loads here, so a lane of a persistent kernel can restart while its wavefront's accesses are in flight (a piece of the
+    // finished block that lands in L afterwards is overwritten by the new block's piece 0, which was issued later: loads return in order).
+    auto start_block = [&](bool act) {
+        skew = (int)((uint64_t)src & (uint64_t)(P - 1));
+        src_al = (uint64_t)src - (uint64_t)skew;
+        in_total = iend > 0 ? (int)(((int64_t)skew + iend + P - 1) & ~(int64_t)(P - 1)) : 0;
+        out_limit = oend > kLastLiterals ? (uint32_t)(oend - kLastLiterals) : 0u;
+        ip = 0; wb = -16 - P; lvalid = 0; pend_a = 0; pend_b = 0; op = 0; fl = 0; oa = lane4;
+        kind = kK4None; rem = 0; off = 8; gready = 0;
+        pv = 0; p_ll = 0; p_st = 0; p_ml = 0; p_off = 0; p_flags = 0; p_res = 0; hdr = 0; token = 0;
+        final_seen = 0; final_run = 0; result = 0; done = 0;
+        if (!act || (!KNOWN && iend == 0)) { done = 1; final_seen = 1; }   // lz4.c:946 returns -(0)
+    };
+    start_block(active);
 
     // Append the low n_ bytes of the data dwords at op: rotated to the byte phase of op (one v_perm_b32 per dword), the
     // first dword merged into the ring under a byte mask, the others stored whole.
@@ -452,8 +457,22 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     };
 
     for (;;) {
-        if (iteration(std::true_type{}, fa, fb, pend_a, pend_b)) break;
-        if (iteration(std::integral_constant<bool, FE == 1>{}, fb, fa, pend_b, pend_a)) break;
+        if (!std::remove_reference<NEXT>::type::kPersistent) {
+            if (iteration(std::true_type{}, fa, fb, pend_a, pend_b)) break;
+            if (iteration(std::integral_constant<bool, FE == 1>{}, fb, fa, pend_b, pend_a)) break;
+        } else {
+            (void)iteration(std::true_type{}, fa, fb, pend_a, pend_b);
+            (void)iteration(std::integral_constant<bool, FE == 1>{}, fb, fa, pend_b, pend_a);
+            // lanes that have finished their block take the next one (a rare, wave-uniform branch: once per block and lane)
+            const bool fin = (done != 0) & (exhausted == 0);
+            if (wv::any(fin)) {
+                if (fin) {
+                    if (next(result, src, iend, dst, oend)) start_block(true);
+                    else exhausted = 1;
+                }
+                if (!wv::any(exhausted == 0)) break;
+            }
+        }
     }
     return result;
 #undef L4_RING
@@ -461,11 +480,31 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 #undef L4_APPEND
 }
 
+// How many blocks of the batch the filter selects (one launch in front of a large partitioned batch): the two lane kernels below
+// look at this number and only ONE of them runs -- one block per lane when (nearly) every block is selected, the persistent grid
+// when many are not (its lanes skip those instead of idling through a whole wavefront's lifetime).
+__global__ void __launch_bounds__(256) count_selected_kernel(Batch b, int filter, unsigned* count)
+{
+    unsigned mine = 0;
+    for (int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x; blk < b.n_blocks; blk += (int64_t)gridDim.x * 256)
+        mine += block_selected(filter, batch_src_len(b, blk), batch_dst_cap(b, blk)) ? 1u : 0u;
+    const unsigned total = wv::scan_add(mine);                       // (inclusive prefix sum: the last lane holds the wavefront's sum)
+    if ((threadIdx.x & 63u) == 63u && total) atomicAdd(count, total);
+}
+// gate_mode 0: run; 1: run only if *gate >= threshold; 2: run only if *gate < threshold
+LZ4HIP_DEVICE bool lane4_gate_open(const unsigned* gate, int gate_mode, unsigned threshold)
+{
+    if (gate_mode == 0) return true;
+    const unsigned c = wv::uniform(*gate);
+    return gate_mode == 1 ? c >= threshold : c < threshold;
+}
+
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.
 template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
-__global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
+__global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter, const unsigned* gate = nullptr, int gate_mode = 0, unsigned threshold = 0)
 {
     LZ4HIP_STATIC_LDS(lds, lane4_lds_bytes(R));
+    if (!lane4_gate_open(gate, gate_mode, threshold)) return;
     const int lane = (int)threadIdx.x;
     const int64_t blk = (int64_t)blockIdx.x * 64 + lane;
     bool active = blk < b.n_blocks;
@@ -479,6 +518,40 @@ __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter)
     uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
     const int r = lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL>(lds, lane, active, src, src_len, dst, out_size);
     if (active) b.result[blk] = r;
+}
+
+// (what a lane of the persistent kernel does between two blocks)
+struct PullNext {
+    static constexpr bool kPersistent = true;
+    const Batch* b; int filter; unsigned long long* counter; int64_t cur;
+    LZ4HIP_DEVICE bool operator()(int r, const uint8_t*& src, int& iend, uint8_t*& dst, int& oend)
+    {
+        if (cur >= 0) b->result[cur] = r;
+        for (;;) {
+            const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
+            if (blk >= b->n_blocks) { cur = -1; return false; }
+            const int sl = batch_src_len(*b, blk), oc = batch_dst_cap(*b, blk);
+            if (!block_selected(filter, sl, oc)) continue;
+            cur = blk; src = batch_src(*b, blk); iend = sl; dst = batch_dst(*b, blk); oend = oc;
+            return true;
+        }
+    }
+};
+
+// Persistent variant: a grid of resident wavefronts whose lanes pull block numbers from `counter` (zeroed by the host) until the
+// batch is exhausted; blocks the filter does not select are skipped by the lane that drew them.
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
+__global__ void __launch_bounds__(64) decode_lane4_persistent_kernel(Batch b, int filter, unsigned long long* counter, const unsigned* gate = nullptr,
+                                                                     int gate_mode = 0, unsigned threshold = 0)
+{
+    LZ4HIP_STATIC_LDS(lds, lane4_lds_bytes(R));
+    if (!lane4_gate_open(gate, gate_mode, threshold)) return;
+    const int lane = (int)threadIdx.x;
+    PullNext next{ &b, filter, counter, -1 };
+    const uint8_t* src = nullptr; uint8_t* dst = nullptr; int src_len = 0, out_size = 0;
+    const bool active = next(0, src, src_len, dst, out_size);
+    if (!wv::any(active)) return;
+    (void)lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL, PullNext&>(lds, lane, active, src, src_len, dst, out_size, next);
 }
 
 }  // namespace lz4hip

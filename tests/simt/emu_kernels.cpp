@@ -108,6 +108,19 @@ void emu_decode_lane4(int known, const uint8_t* src, int64_t src_stride, const i
 #undef EMU_LANE4
 }
 
+// the persistent variant of the default configuration: `groups` wavefronts whose lanes pull blocks from a counter
+void emu_decode_lane4_persistent(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                                 int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int groups)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    static unsigned long long counter;
+    counter = 0;
+    unsigned long long* c = &counter;
+    dim3 grid((unsigned)groups), block(64);
+    if (known) simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<true, 192, 32, 128, 2, 2, 2>(b, filter, c); });
+    else       simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<false, 192, 32, 128, 2, 2, 2>(b, filter, c); });
+}
+
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
                      int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
 {

@@ -101,7 +101,14 @@ inline int rank_below(uint64_t m) { return __builtin_popcountll(m & ((1ull << la
 inline void mem_sync() { simt::yield(simt::WAIT_WAVE, 140); }
 inline void block_sync() { simt::yield(simt::WAIT_BLOCK, 150); }
 inline void lds_barrier() { simt::yield(simt::WAIT_BLOCK, 150); }
-inline void wait_vector_memory() {}                                  // (s_waitcnt vmcnt(0): nothing to wait for on the CPU)
+// s_waitcnt vmcnt(0): every access issued through vm_load16_* / vm_store16_* so far has finished
+inline void wait_vector_memory()
+{
+    auto& q = simt::rt().cur->vmq;
+    for (const simt::PendingVm& op : q)
+        if (op.is_load && op.addr) __builtin_memcpy(op.dst, (const void*)op.addr, 16);
+    q.clear();
+}
 
 inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 {

@@ -12,6 +12,8 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
+    if isinstance(m, str) and m.startswith("l4p"):                   # "l4p2": persistent variant of the default generation-4 configuration, 2 wavefronts
+        return dict(lane=int(m[3:]), gen=5)
     if isinstance(m, str) and m.startswith("l4c"):                   # "l4c1192": fourth-generation lane decoder, ring 192 + 1000 x variant
         return dict(lane=int(m[3:]), gen=4)
     if isinstance(m, str) and m.startswith("l3r"):                   # "l3r240": third-generation lane decoder, ring 240 (staging 64)
@@ -23,7 +25,7 @@ def _mapping(m):
     return {}
 
 
-LANE3 = ["l3r128", "l3r240", "l4c11192", "l4c27192"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
+LANE3 = ["l3r128", "l3r240", "l4c11192", "l4c27192", "l4p1", "l4p3"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
 LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128", "l4c128", "l4c2128", "l4c192", "l4c1192", "l4c3192", "l4c7192", "l4c1256", "l4c2240", "l4c5256", "l4c11192", "l4c15192", "l4c27192", "l4c25192"]
 
 
