@@ -176,12 +176,13 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         else if (op <= o_burst && ip <= i_burst) {
             win.need(ip, 96);
             const int idx0 = ip - win.base, J0 = idx0 >> 2, ph = idx0 & 3;
-            // D: lane i (< 32) holds the window's dword J0 + i;  then this lane's twelve bytes at ip + lane
-            const int di = J0 + (lane & 31);
-            const uint32_t Da = wv::shuffle(win.w0, di & 63), Db = wv::shuffle(win.w1, di & 63);
-            const uint32_t D = (di & 64) ? Db : Da;
-            const int bi = ph + lane, dj = bi >> 2;
-            const uint32_t x0 = wv::shuffle(D, dj), x1 = wv::shuffle(D, dj + 1), x2 = wv::shuffle(D, dj + 2);
+            // this lane's twelve bytes at ip + lane: three window dwords, fetched from both halves of the window in ONE round of
+            // cross-lane reads (a first version went through an intermediate register: two dependent rounds)
+            const int bi = ph + lane, dj = J0 + (bi >> 2);
+            const uint32_t a0 = wv::shuffle(win.w0, dj & 63), b0 = wv::shuffle(win.w1, dj & 63);
+            const uint32_t a1 = wv::shuffle(win.w0, (dj + 1) & 63), b1 = wv::shuffle(win.w1, (dj + 1) & 63);
+            const uint32_t a2 = wv::shuffle(win.w0, (dj + 2) & 63), b2 = wv::shuffle(win.w1, (dj + 2) & 63);
+            const uint32_t x0 = (dj & 64) ? b0 : a0, x1 = ((dj + 1) & 64) ? b1 : a1, x2 = ((dj + 2) & 64) ? b2 : a2;
             const uint32_t sh = (uint32_t)bi & 3u;
             const uint32_t v0 = wv::alignbyte(x1, x0, sh), v1 = wv::alignbyte(x2, x1, sh), v2 = x2 >> (8u * sh);
             const uint32_t tok = v0 & 255u, ll = tok >> 4, mlc = tok & 15u;

@@ -90,6 +90,34 @@ def test_full_size_decode_properties(torch_cuda, oracle, dist):
     _compare_whole_corpus(oracle, batch, comp, clen, False, dist, 7)
 
 
+@pytest.mark.parametrize("n,mix", [(1 << 18, False), (1 << 18, True), (1 << 20, True)], ids=["2^18-homogeneous", "2^18-half-zeros", "2^20-half-zeros"])
+def test_lane_decoder_persistent_grid_and_device_side_choice(torch_cuda, n, mix):
+    """The lane decoder's second form: a persistent grid whose lanes pull blocks from a counter.  The library takes it for batches of
+    one to three residency rounds (2^18 blocks) and, decided ON THE DEVICE by a counting launch, for large batches in which many
+    blocks are routed to the wavefront mapping (every second block zeros: the one-block-per-lane form would run its wavefronts
+    half empty).  Whatever form runs: every result equals the compressed length, every byte the input; the knob's three settings
+    agree."""
+    torch = torch_cuda
+    from lz4net_amd import batch, _lib
+    free, _ = torch.cuda.mem_get_info()
+    while n * (2 * batch.BLOCK + batch.BOUND_STRIDE) * 1.05 > free and n > 4096:
+        n //= 2
+    raw = batch.synth(2, 313, 0, n)
+    if mix:
+        raw[1::2] = 0
+    comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    back = torch.empty_like(raw)
+    for persist in (0, 1, 2):
+        with _lib.tuning(decoder_persist=persist):
+            back.fill_(0x5A)
+            used = batch.decode(comp, clen, back, batch.BLOCK)
+            assert bool((used == clen).all()), persist
+            assert batch.count_mismatches(raw, back, batch.BLOCK) == 0, persist
+            produced = batch.decode(comp, clen, back.fill_(0x5A), batch.BLOCK, known_output_size=False)
+            assert bool((produced == batch.BLOCK).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0, persist
+
+
 def _compare_whole_corpus(oracle, batch, comp, clen, hc, dist, seed, budget=240.0):
     """EVERY block's (compressed length, checksum of the compressed bytes) from the GPU rows against the CPU codec, which
     regenerates the block from its seed, compresses it and keeps only those two numbers (oracle/batch.c
