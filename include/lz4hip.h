@@ -136,7 +136,8 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *   "decoder_persist"            [LZ4HIP_DECODER_PERSIST]  lane decoder: 0 = automatic (one block per lane under hardware dispatch for large batches whose
  *                                 blocks nearly all take the lane mapping; a persistent grid whose lanes pull blocks from a counter for batches of fewer
  *                                 than three residency rounds and for batches with many blocks routed to the wavefront mapping -- counted on the device),
- *                                 1 = always the persistent grid, 2 = never
+ *                                 1 = always the persistent grid, 2 = never;  "decoder_groups" [LZ4HIP_DECODER_GROUPS]: wavefronts of that grid
+ *                                 (0 = the residency; tests use 1 so that every lane restarts hundreds of times)
  *   "hc_sub_chunks"              [LZ4HIP_HC_SUB_CHUNKS]  LZ4HC lane mapping, blocks <= 64 KiB: a chunk of blocks is cut into this many sub-chunks whose
  *                                 table builders and lane kernels overlap on separate streams (0 = default 2, 1 = one after the other, at most 8)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the

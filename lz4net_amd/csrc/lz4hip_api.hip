@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -64,6 +64,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "hc_ctrl_every", "LZ4HIP_HC_CTRL_EVERY", false }, { "hc_ctrl_lanes", "LZ4HIP_HC_CTRL_LANES", false },   // lz4hip_hc_lcp.hpp: control-flow batching (0 default)
     { "hc_sub_chunks", "LZ4HIP_HC_SUB_CHUNKS", false },             // LZ4HC lane launch: sub-chunks whose table builders and lane kernels overlap (0 default = 2, 1 = one after the other, max 8)
     { "decoder_persist", "LZ4HIP_DECODER_PERSIST", false },         // lane decoder, default configuration: 0 the device picks one block per lane or the persistent grid, 1 always persistent, 2 never
+    { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -549,7 +550,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 const unsigned* gate = mode == 2 ? (const unsigned*)(counter + 1) : nullptr;       // (the slot's second qword: the count)
                 const unsigned threshold = (unsigned)(d.n_blocks - d.n_blocks / 10);            // "nearly every block": 90 %
                 if (mode == 2) {
-                    const unsigned cg = (unsigned)((d.n_blocks + 255) / 256 < 4096 ? (d.n_blocks + 255) / 256 : 4096);
+                    const unsigned cg = (unsigned)((d.n_blocks + 255) / 256 < 512 ? (d.n_blocks + 255) / 256 : 512);   // (one atomic per wavefront on ONE address: few, fat wavefronts)
                     hipLaunchKernelGGL(count_selected_kernel, dim3(cg), dim3(256), 0, stream, d, lane_filter, (unsigned*)(counter + 1));
                     HIP_TRY(hipGetLastError());
                 }
@@ -559,7 +560,8 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                     HIP_TRY(hipGetLastError());
                 }
                 if (mode != 0) {
-                    const unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
+                    unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
+                    if (knob(kKnobDecoderGroups) > 0 && (unsigned)knob(kKnobDecoderGroups) < pg) pg = (unsigned)knob(kKnobDecoderGroups);
                     if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
                     else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
                 }

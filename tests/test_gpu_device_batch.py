@@ -118,6 +118,46 @@ def test_lane_decoder_persistent_grid_and_device_side_choice(torch_cuda, n, mix)
             assert bool((produced == batch.BLOCK).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0, persist
 
 
+def test_lane_decoder_persistent_many_restarts(torch_cuda, oracle):
+    """The persistent lane decoder with ONE wavefront in its grid ("decoder_groups" = 1): its 64 lanes decode 12 000 small blocks of
+    mixed sizes and kinds, ~190 restarts per lane, each restart with whatever the finished block left in flight (an input piece
+    requested in its last trips lands AFTER the restart and must be overwritten by the new block's first piece).  EVERY block's
+    bytes and result are compared; blocks of 0 .. 3 000 bytes incl. empty ones, sources at odd addresses."""
+    torch = torch_cuda
+    from lz4net_amd import batch, _lib
+    rng = np.random.default_rng(97)
+    n = 12000
+    sizes = rng.integers(0, 3000, n)
+    sizes[::97] = 0
+    sizes[1::53] = rng.integers(1, 20, len(sizes[1::53]))
+    stride = 3008 + 16
+    raw_h = np.zeros((n, stride), np.uint8)
+    for k, dist in enumerate((2, 3, 1, 0)):
+        rows = oracle.gen(dist, 131 + k, 0, n // 4 + 1, 3000)
+        raw_h[k::4, :3000] = rows[:len(raw_h[k::4])]
+    for i in range(n):
+        raw_h[i, sizes[i]:] = 0
+    raw = torch.from_numpy(raw_h).cuda()
+    slen = torch.from_numpy(sizes.astype(np.int32)).cuda()
+    cstride = 3000 + 3000 // 255 + 16 + 23          # (odd: compressed rows start at odd addresses)
+    comp = torch.zeros((n, cstride), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, slen, comp, 3000 + 3000 // 255 + 16, src_len_hint=3000)
+    assert bool((clen > 0).all())
+    back = torch.full((n, stride), 0x77, dtype=torch.uint8, device="cuda")
+    with ForcedMapping("LZ4HIP_DECODER", "lane"), _lib.tuning(decoder_persist=1, decoder_groups=1):
+        used = batch.decode(comp, clen, back, slen, known_output_size=True)
+        torch.cuda.synchronize()
+        assert bool((used == clen).all())
+        back_h = back.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(back_h[i, :sizes[i]], raw_h[i, :sizes[i]]), i
+            assert (back_h[i, sizes[i]:] == 0x77).all(), (i, "wrote past the block")
+        produced = batch.decode(comp, clen, back.fill_(0x77), slen, known_output_size=False)
+        torch.cuda.synchronize()
+        assert bool((produced == slen).all())
+        assert np.array_equal(back.cpu().numpy(), back_h)
+
+
 def _compare_whole_corpus(oracle, batch, comp, clen, hc, dist, seed, budget=240.0):
     """EVERY block's (compressed length, checksum of the compressed bytes) from the GPU rows against the CPU codec, which
     regenerates the block from its seed, compresses it and keeps only those two numbers (oracle/batch.c
