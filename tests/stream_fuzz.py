@@ -34,7 +34,8 @@ def make_stream(rng, target, tail_kind=0):
             break
         lits = rng.integers(0, 256, ll, dtype=np.uint8).tobytes()
         avail = len(raw) + ll
-        off_choices = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 100, 107, 108, 109, 110, 111, 112, 113, 127, 128, 129, 255, 256, 257, 1000, 4031, 4032, 4033, 4094, 4095, 4096, 4097, 4100, 8192, 65535]
+        off_choices = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 47, 48, 49, 63, 64, 65, 66, 100, 107, 108, 109, 110, 111, 112, 113, 127, 128, 129, 170, 171, 172, 173, 174, 188, 191, 192, 193,
+                       255, 256, 257, 1000, 4031, 4032, 4033, 4094, 4095, 4096, 4097, 4100, 8192, 65535]     # (around every ring / window / burst threshold of the decoders)
         off = int(rng.choice([o for o in off_choices if o <= avail] or [avail])) if style < 9 else int(rng.integers(1, avail + 1))
         out.append((min(ll, 15) << 4) | min(ml - 4, 15))
         if ll >= 15:
