@@ -140,6 +140,11 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 (0 = the residency; tests use 1 so that every lane restarts hundreds of times)
  *   "hc_sub_chunks"              [LZ4HIP_HC_SUB_CHUNKS]  LZ4HC lane mapping, blocks <= 64 KiB: a chunk of blocks is cut into this many sub-chunks whose
  *                                 table builders and lane kernels overlap on separate streams (0 = default 2, 1 = one after the other, at most 8)
+ *   "encoder_slab_tries"         [LZ4HIP_ENCODER_SLAB_TRIES]  fast encoder, lane mapping: its hash tables live in a slab of separately allocated chunks;
+ *                                 when the slab is built (first large batch on a device) the library times a probe kernel on it and, if the placement
+ *                                 is slower than a well spread one, builds up to this many candidates and keeps the fastest (0 = default 4;
+ *                                 1 = the first candidate, unmeasured).  Read-only through lz4hip_tuning_get: "encoder_slab_rate" (what the
+ *                                 current device's slab measured, 1000 x G probe steps per second; 0 = none / unmeasured), "encoder_slab_tried"
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -65,6 +65,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "hc_sub_chunks", "LZ4HIP_HC_SUB_CHUNKS", false },             // LZ4HC lane launch: sub-chunks whose table builders and lane kernels overlap (0 default = 2, 1 = one after the other, max 8)
     { "decoder_persist", "LZ4HIP_DECODER_PERSIST", false },         // lane decoder, default configuration: 0 the device picks one block per lane or the persistent grid, 1 always persistent, 2 never
     { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
+    { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -220,6 +221,119 @@ int lease_end(Lease& l, hipStream_t stream)
     return 0;
 }
 
+// The lane encoder's table slab (lz4hip_encode_lane.hpp): equally sized chunks, separate allocations, because the kernel's rate is the
+// device's rate of random sector read-modify-writes and that depends on how the slab is spread over device memory (20.5 G steps per second
+// inside one contiguous 8 GiB allocation, 25-27 G spread out: profiles/r04/random_sectors_*.txt).  Where an allocation lands cannot be
+// asked for, but it can be MEASURED: a candidate set of chunks is built and timed with slab_probe_kernel (a few milliseconds); if it is
+// slower than a well spread slab, up to three more are built next to it and the fastest stays (fast_slab_reserve).
+// One-time work per device and slab size; protected by the g_fast_ws lease.
+struct FastSlab {
+    std::vector<void*> chunks;
+    unsigned tables_per_chunk = 0;   // a multiple of 64
+    int64_t groups = 0;              // wavefronts the slab has tables for
+    void* ctl = nullptr;             // device: the work counter (256 bytes), then the chunk pointers
+    double probe = 0;                // G steps per second the placement measured (0: not measured)
+    int tries = 0;
+    void release()
+    {
+        for (void* c : chunks) (void)hipFree(c);
+        chunks.clear();
+        if (ctl) { (void)hipFree(ctl); ctl = nullptr; }
+        groups = 0; tables_per_chunk = 0; probe = 0; tries = 0;
+    }
+};
+FastSlab g_fast_slab[64];
+constexpr int kFastSlabMaxChunks = 64;
+constexpr size_t kFastSlabCtlBytes = 256 + 8 * kFastSlabMaxChunks;
+
+// One candidate: n_chunks separate allocations of chunk_bytes.
+bool fast_slab_candidate(int n_chunks, size_t chunk_bytes, std::vector<void*>& out)
+{
+    for (int k = 0; k < n_chunks; k++) {
+        void* c = nullptr;
+        if (hipMalloc(&c, chunk_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void* q : out) (void)hipFree(q);
+            out.clear();
+            return false;
+        }
+        out.push_back(c);
+    }
+    return true;
+}
+
+// Makes the device's slab hold tables for `groups` wavefronts (nonzero return: could not be allocated; the lease stays valid).
+int fast_slab_reserve(Lease& l, int dev, int64_t groups)
+{
+    FastSlab& fs = g_fast_slab[dev];
+    if (fs.groups >= groups && fs.ctl) return 0;
+    if (fs.ctl) { HIP_TRY(hipDeviceSynchronize()); fs.release(); l.w->busy = false; }
+    const size_t tables = (size_t)groups * 64;
+    const bool large = tables * (size_t)kLaneTableBytes >= ((size_t)2 << 30);   // below 2 GiB: one chunk, nothing to measure
+    const int want_tries = !large ? 1 : (knob(kKnobEncoderSlabTries) > 0 ? knob(kKnobEncoderSlabTries) : 4);
+    void* ctl = nullptr;
+    if (hipMalloc(&ctl, kFastSlabCtlBytes) != hipSuccess) { (void)hipGetLastError(); return fail(LZ4HIP_E_MEMORY, "workspace allocation failed"); }
+    hipStream_t ps = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    unsigned* sink = (unsigned*)((uint8_t*)ctl + 128);
+    if (want_tries > 1 && (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
+        (void)hipGetLastError();
+        if (ps) (void)hipStreamDestroy(ps);
+        if (e0) (void)hipEventDestroy(e0);
+        ps = nullptr;                                                 // (no measurement then: the first candidate stays)
+    }
+    // Candidates: 16 chunks allocated back to back (64 for the third one).  A candidate that measures below the rate of a well spread slab
+    // stays allocated while the next one is built -- so that the next one lands elsewhere -- and all but the best are freed at the end
+    // (spacer allocations between the chunks spread further but cost seconds: tools/r04/call24.sh, first version).
+    const double good = 24.0 * ((double)tables < 262144.0 ? (double)tables / 262144.0 : 1.0);   // G steps per second (profiles/r04/random_sectors_*.txt: 20.5 in one piece, 25-27 spread)
+    std::vector<std::vector<void*>> held;
+    std::vector<void*> best;
+    unsigned best_tpc = 0;
+    double best_rate = -1;
+    int tried = 0;
+    for (int r = 0; r < want_tries; r++) {
+        const int n_chunks = !large ? 1 : (r == 2 ? 64 : 16);
+        const unsigned tpc = (unsigned)(((groups + n_chunks - 1) / n_chunks) * 64);
+        if (r > 0) {                                                   // a further candidate only while it leaves half of the free memory alone
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+            if ((size_t)n_chunks * tpc * (size_t)kLaneTableBytes > free_b / 2) break;
+        }
+        std::vector<void*> cand;
+        if (!fast_slab_candidate(n_chunks, (size_t)tpc * (size_t)kLaneTableBytes, cand)) break;
+        tried++;
+        double rate = 0;
+        if (ps && want_tries > 1) {
+            bool ok = hipMemcpyAsync((uint8_t*)ctl + 256, cand.data(), 8 * cand.size(), hipMemcpyHostToDevice, ps) == hipSuccess
+                   && hipStreamSynchronize(ps) == hipSuccess;
+            const int steps = 300;
+            if (ok) {
+                hipLaunchKernelGGL(slab_probe_kernel, dim3((unsigned)groups), dim3(64), 0, ps, (uint8_t* const*)((uint8_t*)ctl + 256), tpc, 30, sink);   // (warm-up)
+                ok = hipEventRecord(e0, ps) == hipSuccess;
+                hipLaunchKernelGGL(slab_probe_kernel, dim3((unsigned)groups), dim3(64), 0, ps, (uint8_t* const*)((uint8_t*)ctl + 256), tpc, steps, sink);
+                ok = ok && hipEventRecord(e1, ps) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0;
+                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) rate = (double)tables * steps / ms / 1e6;
+            }
+            if (!ok) (void)hipGetLastError();
+        }
+        if (rate > best_rate) { best.swap(cand); best_tpc = tpc; best_rate = rate; }   // (cand now holds the set that lost)
+        if (!cand.empty()) held.push_back(std::move(cand));
+        if (rate >= good || rate == 0) break;
+    }
+    for (auto& h : held) for (void* c : h) (void)hipFree(c);
+    if (ps) { (void)hipStreamDestroy(ps); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    if (best.empty()) { (void)hipFree(ctl); return fail(LZ4HIP_E_MEMORY, "workspace allocation failed"); }
+    if (hipMemcpy((uint8_t*)ctl + 256, best.data(), 8 * best.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        for (void* c : best) (void)hipFree(c);
+        (void)hipFree(ctl);
+        return fail(LZ4HIP_E_DEVICE, "workspace set-up failed");
+    }
+    fs.chunks.swap(best); fs.tables_per_chunk = best_tpc; fs.groups = groups; fs.ctl = ctl; fs.probe = best_rate > 0 ? best_rate : 0; fs.tries = tried;
+    return 0;
+}
+
 // Streams and events of the pipelined LZ4HC lane launch (one set per device, created on first use; the workspace lease
 // serialises its users).
 constexpr int kHcSubChunks = 2, kHcMaxSubChunks = 8;   // measured at 2^18 blocks (profiles/r04/hc_sub_chunks.txt): 1 -> 15.9 / 20.8 GB/s (D2 / D3), 2 -> 16.8 / 23.2, 4 -> 15.1 / 21.0, 8 -> 11.6 / 16.7
@@ -261,7 +375,8 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         char pick = d.n_blocks >= kLaneEncodeMinBlocks ? 'a' : 'w';  // 'a': both launches
         if (force) pick = force == 1 ? 'w' : 'l';
         Lease lease;
-        void* ws = nullptr;
+        void* ws = nullptr;                                           // the slab's control block: work counter, then the chunk pointers
+        unsigned slab_tpc = 0;
         int64_t groups = 0;
         if (pick != 'w') {
             int dev = 0, cus = 0;
@@ -272,10 +387,11 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             if (rc) return rc;
             // the slab holds one table per resident lane; if it cannot be had, halve the residency, and
             // in the end fall back to the wavefront mapping (which needs no workspace)
+            if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
             for (; wpc >= 1; wpc /= 2) {
                 groups = (int64_t)cus * wpc;
                 if (groups > (d.n_blocks + 63) / 64) groups = (d.n_blocks + 63) / 64;
-                if (lease_reserve(lease, (size_t)groups * 64 * (size_t)kLaneTableBytes + 256) == 0) { ws = lease.p; break; }
+                if (fast_slab_reserve(lease, dev, groups) == 0) { ws = g_fast_slab[dev].ctl; slab_tpc = g_fast_slab[dev].tables_per_chunk; break; }
             }
             if (!ws) { lease.lock.unlock(); pick = 'w'; }
         }
@@ -289,7 +405,7 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             lease.queued = true;
             HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
             hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                               (unsigned long long*)ws, (uint8_t*)ws + 256, pick == 'a' ? 1 : 0);
+                               (unsigned long long*)ws, (uint8_t* const*)((uint8_t*)ws + 256), slab_tpc, pick == 'a' ? 1 : 0);
             HIP_TRY(hipGetLastError());
             count_dispatch(LZ4HIP_K_ENCODE_LANE);
             int rc = lease_end(lease, stream);
@@ -458,7 +574,13 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         // first 8 bytes of the workspace: the work counter of the persistent grid
         lease.queued = true;
         HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-        if (!small) HIP_TRY(hipFuncSetAttribute((const void*)encode_hc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if (!small) {
+            static std::atomic<bool> attr_set[64];                    // once per device, not per launch
+            if (!attr_set[dev].load(std::memory_order_acquire)) {
+                HIP_TRY(hipFuncSetAttribute((const void*)encode_hc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+                attr_set[dev].store(true, std::memory_order_release);
+            }
+        }
         hipLaunchKernelGGL(encode_hc_kernel, dim3((unsigned)groups), dim3(64), lds_bytes, stream, d,
                            (unsigned long long*)ws, (uint8_t*)ws + 256, lds_bytes);
         HIP_TRY(hipGetLastError());
@@ -911,7 +1033,6 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
     }
 
     auto src_row = [&](int64_t i) { return (const uint8_t*)hb->src + (hb->src_off ? hb->src_off[i] : i * hb->src_stride); };
-    auto dst_row = [&](int64_t i) { return (uint8_t*)hb->dst + (hb->dst_off ? hb->dst_off[i] : i * hb->dst_stride); };
     auto src_len = [&](int64_t i) { return hb->src_len ? hb->src_len[i] : hb->src_len_all; };
     auto dst_cap = [&](int64_t i) { return hb->dst_cap ? hb->dst_cap[i] : hb->dst_cap_all; };
 
@@ -1171,6 +1292,11 @@ int lz4hip_release_workspaces(void)
     for (HcWorkspace* pool : { g_hc_ws, g_fast_ws }) {
         HcWorkspace& w = pool[dev];
         std::unique_lock<std::mutex> lock(w.mu);
+        if (pool == g_fast_ws && g_fast_slab[dev].ctl) {             // (the lane encoder's slab hangs off the same lease)
+            if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
+            g_fast_slab[dev].release();
+            w.busy = false;
+        }
         if (!w.p) continue;
         if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
         HIP_TRY(hipFree(w.p));
@@ -1211,6 +1337,14 @@ int lz4hip_tuning_set(const char* name, int value)
 int lz4hip_tuning_get(const char* name)
 {
     knobs_init();
+    // read-only: what the placement of the current device's lane-encoder slab measured, in M steps per second (0: no slab yet or not measured),
+    // and how many candidate placements were built
+    if (name && (strcmp(name, "encoder_slab_rate") == 0 || strcmp(name, "encoder_slab_tried") == 0)) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+        std::lock_guard<std::mutex> lk(g_fast_ws[dev].mu);
+        return name[13] == 'r' ? (int)(g_fast_slab[dev].probe * 1000.0) : g_fast_slab[dev].tries;
+    }
     for (int k = 0; name && k < kKnobCount; k++)
         if (strcmp(name, kKnobInfo[k].name) == 0) return g_knob[k].load(std::memory_order_relaxed);
     return fail(LZ4HIP_E_ARGUMENT, std::string("unknown knob ") + (name ? name : "(null)"));

@@ -237,7 +237,7 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                     }
                     if (live) { dst[op + lane] = (uint8_t)val; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)val; }
                     wv::mem_sync();
-                    LZ4HIP_STAT(20, lane == 0); LZ4HIP_STAT_ADD(21, lane == 0 ? wv::popc64(tok_m) : 0); LZ4HIP_STAT_ADD(22, lane == 0 ? rounds : 0);
+                    LZ4HIP_STAT(20, lane == 0); LZ4HIP_STAT_ADD(21, lane == 0 ? wv::popc64(tok_m) : 0); LZ4HIP_STAT_ADD(22, lane == 0 ? rounds : 0); (void)rounds;
                     ip += s_tok; op += tot;
                     burst_done = true;
                     burst_fail = 0;

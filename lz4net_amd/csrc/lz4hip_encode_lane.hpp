@@ -246,11 +246,17 @@ tail:
 }
 
 // Persistent grid: every lane pulls block indices from `counter` until the batch is exhausted.
-// `tables` holds kLaneTableBytes of hash table per lane of the grid.
+// The slab -- kLaneTableBytes of hash table per lane of the grid -- is a set of equally sized CHUNKS, separate allocations: table g lives
+// in chunk g / tables_per_chunk (a multiple of 64: one chunk per wavefront).  Why chunks: the rate of this kernel is the device's rate of
+// random 64-byte read-modify-writes, and that rate depends on how the slab is spread over device memory -- 20.5 G per second inside one
+// contiguous 8 GiB allocation, 25-27 G when it is spread (tools/microbench_random_sectors*.hip, profiles/r04/random_sectors_*.txt; the
+// "two rates" of this encoder, 44-46 and 53-54 GB/s, were whether its one allocation happened to straddle such a boundary).  The host
+// side builds a few candidate sets of chunks, measures each with slab_probe_kernel and keeps the fastest (launch_encode).
 // only_deferred != 0: just the blocks the wavefront-per-block launch handed over (result[] == kDeferredResult).
-__global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* tables, int only_deferred)
+__global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* const* chunks, unsigned tables_per_chunk, int only_deferred)
 {
-    uint8_t* table = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLaneTableBytes;
+    const unsigned g = blockIdx.x * 64u + threadIdx.x;
+    uint8_t* table = chunks[g / tables_per_chunk] + (size_t)(g % tables_per_chunk) * kLaneTableBytes;
     int epoch = 63;                                                   // the slab's contents are unknown at launch
     for (;;) {
         const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
@@ -262,6 +268,25 @@ __global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned 
         b.result[blk] = n < k64kLimit ? lane_encode_fast_block<false>(src, n, dst, cap, table, epoch)      // lz4.c:783-785
                                       : lane_encode_fast_block<true>(src, n, dst, cap, table, epoch);
     }
+}
+
+// What the slab's placement is worth: every lane of the encoder's grid performs `steps` DEPENDENT random 4-byte read-modify-writes inside its
+// own table -- the encoder's memory behaviour without the encoder (one sector in, one sector out per step, nothing stays in a cache).  Timed by
+// the host with events; leaves garbage in the tables (the encoder zeroes a table before its first use: epoch 63).
+__global__ void __launch_bounds__(64) slab_probe_kernel(uint8_t* const* chunks, unsigned tables_per_chunk, int steps, unsigned* sink)
+{
+    const unsigned g = blockIdx.x * 64u + threadIdx.x;
+    uint32_t* const p = (uint32_t*)(chunks[g / tables_per_chunk] + (size_t)(g % tables_per_chunk) * kLaneTableBytes);
+    uint32_t s = g * 2654435761u + 12345u, acc = 0;
+    for (int i = 0; i < steps; i++) {
+        s = s * 1664525u + 1013904223u;
+        const uint32_t off = (s >> 4) % (uint32_t)(kLaneTableBytes / 4);
+        const uint32_t v = p[off];
+        p[off] = v + (uint32_t)i;
+        s ^= v * 0x9E3779B9u;                                        // the next address depends on what was read
+        acc += v;
+    }
+    if (acc == 0x12345678u) *sink = acc;
 }
 
 }  // namespace lz4hip

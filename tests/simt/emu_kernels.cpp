@@ -148,12 +148,18 @@ void emu_encode_fast_lane(const uint8_t* src, int64_t src_stride, const int32_t*
                           int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups)
 {
     Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    // the slab as the library builds it: equally sized chunks, a wavefront's tables never split (here: two wavefronts per chunk, chunks out of order)
+    const unsigned tables_per_chunk = 128;
+    const int n_chunks = (groups * 64 + (int)tables_per_chunk - 1) / (int)tables_per_chunk;
     static std::vector<uint8_t> ws;
-    ws.assign(256 + (size_t)groups * 64 * kLaneTableBytes, 0x5A);     // poisoned: the kernel must zero its tables
+    ws.assign(256 + (size_t)n_chunks * tables_per_chunk * kLaneTableBytes, 0x5A);     // poisoned: the kernel must zero its tables
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
-    uint8_t* tables = ws.data() + 256;
-    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables, 0); });
+    static std::vector<uint8_t*> chunks;
+    chunks.clear();
+    for (int c = 0; c < n_chunks; c++) chunks.push_back(ws.data() + 256 + (size_t)(n_chunks - 1 - c) * tables_per_chunk * kLaneTableBytes);
+    uint8_t* const* cp = chunks.data();
+    simt::launch(dim3((unsigned)groups), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, cp, tables_per_chunk, 0); });
 }
 
 // The two launches of a large batch (launch_encode, 'a'): one wavefront per block with the hand-over rule, then one lane
@@ -168,8 +174,10 @@ void emu_encode_fast_two_launches(const uint8_t* src, int64_t src_stride, const 
     ws.assign(256 + (size_t)64 * kLaneTableBytes, 0x5A);
     memset(ws.data(), 0, 256);
     unsigned long long* counter = (unsigned long long*)ws.data();
-    uint8_t* tables = ws.data() + 256;
-    simt::launch(dim3(1), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, tables, 1); });
+    static uint8_t* one_chunk[1];
+    one_chunk[0] = ws.data() + 256;
+    uint8_t* const* cp = one_chunk;
+    simt::launch(dim3(1), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, cp, 64u, 1); });
 }
 
 #ifdef LZ4HIP_HAVE_HC

@@ -322,6 +322,51 @@ def test_lane_encoder_many_blocks_per_lane(torch_cuda, oracle):
         assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
 
 
+def test_lane_encoder_slab_chunks_measured_and_rebuilt(torch_cuda, oracle):
+    """The lane encoder's table slab is a set of separately allocated chunks whose placement the library measures.  A batch
+    that needs the full residency (16 wavefronts per CU: 16 or 64 chunks) must give the oracle's bytes; the slab reports its measured rate and how
+    many candidates were built; lz4hip_release_workspaces gives the chunks back (free memory returns) and the next call builds a slab again --
+    this time the first candidate, unmeasured (knob encoder_slab_tries = 1) -- with the same bytes."""
+    torch = torch_cuda
+    from lz4net_amd import batch, _lib
+    n, length = 1 << 18, 1024                                        # 2^18 blocks = one per lane of the full grid
+    bound = length + length // 255 + 16
+    raw = batch.synth(2, 77, 0, n, length=length)
+    comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().lz4hip_release_workspaces())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    with ForcedMapping("LZ4HIP_ENCODER", "lane"):
+        clen = batch.encode(raw, length, comp, bound)
+        torch.cuda.synchronize()
+        held = free0 - torch.cuda.mem_get_info()[0]
+        assert held >= 8 << 30, "the slab of a full grid is 8 GiB of tables"
+        tried, rate = _lib.tuning_get("encoder_slab_tried"), _lib.tuning_get("encoder_slab_rate")
+        assert 1 <= tried <= 4 and rate > 5000, (tried, rate)        # measured: G steps per second x 1000 (20 000 .. 27 000 on an MI355X)
+        first = comp.clone()
+        _lib.check(_lib.lib().lz4hip_release_workspaces())
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] < 1 << 30, "the chunks were not given back"
+        assert _lib.tuning_get("encoder_slab_tried") == 0
+        comp.zero_()
+        with _lib.tuning(encoder_slab_tries=1):
+            clen2 = batch.encode(raw, length, comp, bound)
+        torch.cuda.synchronize()
+        assert _lib.tuning_get("encoder_slab_tried") == 1 and _lib.tuning_get("encoder_slab_rate") == 0
+    assert bool((clen == clen2).all())
+    lens = clen.cpu().numpy()
+    assert bool((clen > 0).all())
+    width = int(lens.max())
+    assert bool(torch.equal(first[:, :width] * (torch.arange(width, device="cuda")[None, :] < clen[:, None]),
+                            comp[:, :width] * (torch.arange(width, device="cuda")[None, :] < clen2[:, None])))
+    for i in list(range(0, n, 32749)) + [n - 1]:
+        want = oracle.compress(oracle.gen(2, 77, i, 1, length=length)[0])
+        assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
+    back = torch.empty_like(raw)
+    used = batch.decode(comp, clen2, back, length)
+    assert bool((used == clen2).all()) and batch.count_mismatches(raw, back, length) == 0
+
+
 def test_fast_encode_default_dispatch_two_launches(torch_cuda, oracle):
     """Default dispatch of a large fast-encode batch: the wavefront mapping runs over every block and hands the blocks made
     of short sequences over to the lane mapping.  A batch mixing incompressible, fuzzer-style, record-like and zero blocks
