@@ -79,8 +79,9 @@ def parse_args():
     ap.add_argument("--encoder", choices=["auto", "lane", "wave"], default="auto")
     ap.add_argument("--dst-pad", type=int, default=0, help="extra bytes between decoded blocks (stride experiment)")
     ap.add_argument("--early-workspace", type=int, default=0,
-                    help="1: allocate the lane encoder's table slab BEFORE the batch buffers; 0 (default): when first needed -- measured: the early "
-                         "slab is the SLOW placement (44-46 GB/s in 5 of 6 fresh processes, late 53-54 in 5 of 6; profiles/r04/encoder_reproducibility.txt)")
+                    help="1: make the library build the lane encoder's table slab BEFORE the batch buffers are allocated; 0 (default): when first needed.  "
+                         "(A round-4 experiment from when the slab was ONE allocation whose placement decided between 44-46 and 53-54 GB/s; the slab is now "
+                         "built from separately allocated chunks whose placement the library measures: DESIGN.md 4.2)")
     ap.add_argument("--verify-budget", type=float, default=45.0,
                     help="seconds of host time for EACH full-corpus encoder check against the CPU reference (0 = skip)")
     return ap.parse_args()
