@@ -367,6 +367,40 @@ def test_lane_encoder_slab_chunks_measured_and_rebuilt(torch_cuda, oracle):
     assert bool((used == clen2).all()) and batch.count_mismatches(raw, back, length) == 0
 
 
+def test_lane_encoder_slab_under_memory_pressure(torch_cuda, oracle):
+    """With ~5 GiB of device memory free the 8 GiB slab of the full residency cannot be had: a candidate fails half way through its chunks (they are
+    given back), the launch halves the residency until a slab fits, and the bytes are still the oracle's."""
+    torch = torch_cuda
+    from lz4net_amd import batch, _lib
+    n, length = 1 << 18, 1024
+    bound = length + length // 255 + 16
+    raw = batch.synth(2, 78, 0, n, length=length)
+    comp = torch.empty((n, bound + 15), dtype=torch.uint8, device="cuda")
+    back = torch.empty_like(raw)
+    _lib.check(_lib.lib().lz4hip_release_workspaces())
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    hog = torch.empty(free0 - (5 << 30), dtype=torch.uint8, device="cuda")
+    try:
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free1 < 6 << 30
+        with ForcedMapping("LZ4HIP_ENCODER", "lane"):
+            clen = batch.encode(raw, length, comp, bound)
+        torch.cuda.synchronize()
+        held = free1 - torch.cuda.mem_get_info()[0]
+        assert (1 << 30) <= held <= free1, held                      # a slab of a lower residency (4 GiB or 2 GiB), not the 8 GiB one
+        used = batch.decode(comp, clen, back, length)
+        assert bool((clen > 0).all()) and bool((used == clen).all()) and batch.count_mismatches(raw, back, length) == 0
+        lens = clen.cpu().numpy()
+        for i in list(range(0, n, 32719)) + [n - 1]:
+            want = oracle.compress(oracle.gen(2, 78, i, 1, length=length)[0])
+            assert lens[i] == len(want) and np.array_equal(comp[i, :lens[i]].cpu().numpy(), want), i
+    finally:
+        del hog
+        _lib.check(_lib.lib().lz4hip_release_workspaces())
+        torch.cuda.empty_cache()
+
+
 def test_fast_encode_default_dispatch_two_launches(torch_cuda, oracle):
     """Default dispatch of a large fast-encode batch: the wavefront mapping runs over every block and hands the blocks made
     of short sequences over to the lane mapping.  A batch mixing incompressible, fuzzer-style, record-like and zero blocks
