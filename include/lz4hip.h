@@ -83,7 +83,13 @@ typedef struct lz4hip_batch {
 } lz4hip_batch_t;
 
 /* Device-resident batches: every pointer in *b is device memory of the CURRENT device; the call only
- * enqueues kernels on `stream` (a hipStream_t, NULL = default stream) and returns 0 or LZ4HIP_E_*. */
+ * enqueues kernels on `stream` (a hipStream_t, NULL = default stream) and returns 0 or LZ4HIP_E_*.
+ * One exception, once per device and size: the FIRST fast-encode batch of >= 16384 blocks on a device (and a later one that needs
+ * more resident wavefronts than any before) builds the lane encoder's table slab inside the call -- device allocations, for
+ * slabs >= 2 GiB a few timed probe launches (hipEventSynchronize) on a stream of the library's own, and, when a smaller slab is
+ * replaced, one hipDeviceSynchronize before that one is freed (it stays in place if the larger one cannot be had): 0.1 - 3.5 s
+ * during which the calling thread blocks and holds the device's encoder workspace.  LZ4HC batches likewise
+ * allocate their tables on first use (hipMalloc only).  Every later call is launch-only. */
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream);
 int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream);
 
@@ -120,7 +126,7 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 persistent lane-per-block encoder grids (0 = built-in default)
  *   "hc_groups"                  [LZ4HIP_HC_GROUPS]  wavefronts of the LZ4HC lane grid (0 = from the residency)
  *   "host_threads", "host_slices" [LZ4HIP_HOST_THREADS, LZ4HIP_HOST_SLICES]  host-pointer batches: threads of the process-wide row pool that gathers /
- *                                 scatters rows (0 = min(hardware threads / 4, 64); read when the pool starts a thread), slices per batch
+ *                                 scatters rows (0 = a quarter of the hardware threads, at least 8 and at most 64, never more than the host has; read when the pool starts a thread), slices per batch
  *   "decoder_gen", "decoder_ring" [LZ4HIP_DECODER_GEN, LZ4HIP_DECODER_RING]  lane decoder generation (0 default = 4, lz4hip_decode_lane4.hpp;
  *                                 2 and 3 exist only in libraries built with -DLZ4HIP_TUNING_BUILD) and, for generation 4, its
  *                                 configuration: bytes of output ring per lane + 1000 x variant (bit 0: 128-byte flush units,

@@ -178,11 +178,15 @@ struct Lease {
     void* p = nullptr;
     hipStream_t stream = nullptr;
     bool queued = false;         // kernels that use the workspace have been queued on `stream`
+    std::vector<hipStream_t> side;   // ... and on these streams of the library's own (the LZ4HC sub-chunk pipeline)
     // An error return between the first launch and lease_end() must not leave those kernels unaccounted for: the next user
-    // (possibly on another stream) would overwrite tables that are still being read.
+    // (possibly on another stream) would overwrite tables that are still being read.  Work on the side streams is not behind
+    // `stream` yet on that path, so it is waited for here (an error path: blocking the host is acceptable).
     ~Lease()
     {
-        if (w && lock.owns_lock() && queued && w->last && hipEventRecord(w->last, stream) == hipSuccess) w->busy = true;
+        if (!(w && lock.owns_lock() && queued)) return;
+        for (hipStream_t s : side) (void)hipStreamSynchronize(s);
+        if (w->last && hipEventRecord(w->last, stream) == hipSuccess) w->busy = true;
     }
 };
 
@@ -267,7 +271,7 @@ int fast_slab_reserve(Lease& l, int dev, int64_t groups)
 {
     FastSlab& fs = g_fast_slab[dev];
     if (fs.groups >= groups && fs.ctl) return 0;
-    if (fs.ctl) { HIP_TRY(hipDeviceSynchronize()); fs.release(); l.w->busy = false; }
+    // (a smaller slab that is already there stays until the larger one is built: a failure leaves the old one in place)
     const size_t tables = (size_t)groups * 64;
     const bool large = tables * (size_t)kLaneTableBytes >= ((size_t)2 << 30);   // below 2 GiB: one chunk, nothing to measure
     const int want_tries = !large ? 1 : (knob(kKnobEncoderSlabTries) > 0 ? knob(kKnobEncoderSlabTries) : 4);
@@ -330,6 +334,11 @@ int fast_slab_reserve(Lease& l, int dev, int64_t groups)
         (void)hipFree(ctl);
         return fail(LZ4HIP_E_DEVICE, "workspace set-up failed");
     }
+    if (fs.ctl) {                                                    // the old, smaller slab: its last user first
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        fs.release();
+        l.w->busy = false;
+    }
     fs.chunks.swap(best); fs.tables_per_chunk = best_tpc; fs.groups = groups; fs.ctl = ctl; fs.probe = best_rate > 0 ? best_rate : 0; fs.tries = tried;
     return 0;
 }
@@ -340,8 +349,8 @@ constexpr int kHcSubChunks = 2, kHcMaxSubChunks = 8;   // measured at 2^18 block
 constexpr size_t kHcCounterBytes = 256 * kHcMaxSubChunks;
 struct HcPipe {
     bool ready = false;
-    hipStream_t build = nullptr, lane[kHcMaxSubChunks];
-    hipEvent_t start = nullptr, built[kHcMaxSubChunks], done[kHcMaxSubChunks];
+    hipStream_t build = nullptr, lane[kHcMaxSubChunks] = {};
+    hipEvent_t start = nullptr, built[kHcMaxSubChunks] = {}, done[kHcMaxSubChunks] = {};
     int init()
     {
         if (ready) return 0;
@@ -354,6 +363,18 @@ struct HcPipe {
         }
         ready = true;
         return 0;
+    }
+    // (lz4hip_release_workspaces, under the LZ4HC workspace's lock, after its last user's event)
+    void release()
+    {
+        if (build) { (void)hipStreamDestroy(build); build = nullptr; }
+        if (start) { (void)hipEventDestroy(start); start = nullptr; }
+        for (int k = 0; k < kHcMaxSubChunks; k++) {
+            if (lane[k]) { (void)hipStreamDestroy(lane[k]); lane[k] = nullptr; }
+            if (built[k]) { (void)hipEventDestroy(built[k]); built[k] = nullptr; }
+            if (done[k]) { (void)hipEventDestroy(done[k]); done[k] = nullptr; }
+        }
+        ready = false;
     }
 };
 HcPipe g_hc_pipe[64];
@@ -488,6 +509,8 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 const size_t entry = hc_gen == 4 ? kHcLcpTableBytes : kHcNatChainBytes;
                 uint8_t* const tables = (uint8_t*)ws + kHcCounterBytes;
                 lease.queued = true;
+                lease.side.assign(hp.lane, hp.lane + kHcMaxSubChunks);
+                lease.side.push_back(hp.build);
                 HIP_TRY(hipMemsetAsync(ws, 0, kHcCounterBytes, stream));          // one work counter per sub-chunk (256 bytes apart)
                 for (int64_t first = 0; first < d.n_blocks; first += chunk) {
                     const int64_t cnt = d.n_blocks - first < chunk ? d.n_blocks - first : chunk;
@@ -593,19 +616,38 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
     return 0;
 }
 
-// Work counters of the persistent lane decoder: a small per-device ring of 256-byte slots, one per launch in flight (a slot is
-// reused after 64 further launches on that device).
-int decoder_counter(int dev, hipStream_t stream, unsigned long long** out)
+// Work counters of the persistent lane decoder: a small per-device ring of 256-byte slots, one per launch in flight.  A slot comes
+// back into use after 64 further launches on that device, possibly on another stream, so each slot carries an event that its
+// user records after the last kernel that reads it: the next user's stream waits for that event before it zeroes the slot, and
+// the slot's mutex is held from the zeroing to the record (a second host thread that draws the same slot waits for the
+// first one's record, not just for its launch).  GPU-side ordering only; a stream never waits unless 64 launches are in flight.
+struct CounterSlot { std::mutex mu; hipEvent_t done = nullptr; bool used = false; };
+struct CounterRing { void* mem = nullptr; CounterSlot slot[64]; std::atomic<unsigned> next{ 0 }; std::mutex mu; };
+CounterRing g_counter_ring[64];
+struct CounterLease {
+    CounterSlot* s = nullptr;
+    std::unique_lock<std::mutex> lock;
+    hipStream_t stream = nullptr;
+    // (also on error returns: whatever was queued on `stream` so far is what may still touch the slot)
+    ~CounterLease() { if (s && lock.owns_lock() && s->done && hipEventRecord(s->done, stream) == hipSuccess) s->used = true; }
+};
+int decoder_counter(int dev, hipStream_t stream, unsigned long long** out, CounterLease& lease)
 {
-    static void* ring[64];
-    static std::atomic<unsigned> next[64];
-    static std::mutex mu;
     if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+    CounterRing& r = g_counter_ring[dev];
+    void* mem = nullptr;
     {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!ring[dev]) HIP_TRY(hipMalloc(&ring[dev], 64 * 256));
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (!r.mem) HIP_TRY(hipMalloc(&r.mem, 64 * 256));
+        mem = r.mem;
     }
-    uint8_t* slot = (uint8_t*)ring[dev] + 256 * (size_t)(next[dev].fetch_add(1) & 63u);
+    const unsigned k = r.next.fetch_add(1) & 63u;
+    lease.s = &r.slot[k];
+    lease.stream = stream;
+    lease.lock = std::unique_lock<std::mutex>(lease.s->mu);
+    if (!lease.s->done) HIP_TRY(hipEventCreateWithFlags(&lease.s->done, hipEventDisableTiming));
+    if (lease.s->used) HIP_TRY(hipStreamWaitEvent(stream, lease.s->done, 0));
+    uint8_t* slot = (uint8_t*)mem + 256 * (size_t)k;
     HIP_TRY(hipMemsetAsync(slot, 0, 16, stream));                   // work counter + selected-block count
     *out = (unsigned long long*)slot;
     return 0;
@@ -668,7 +710,8 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 // (a batch that fits the residency in one round gives every lane one block either way: nothing to refill, no counter needed)
                 int mode = persist == 1 ? 1 : ((int64_t)grid <= capacity ? 0 : ((int64_t)grid < 3 * capacity ? 1 : (lane_filter == kAllBlocks ? 0 : 2)));
                 unsigned long long* counter = nullptr;
-                if (mode != 0) { int rc = decoder_counter(dev, stream, &counter); if (rc) return rc; }
+                CounterLease counter_lease;                              // (its destructor records the slot's event behind the kernels queued below)
+                if (mode != 0) { int rc = decoder_counter(dev, stream, &counter, counter_lease); if (rc) return rc; }
                 const unsigned* gate = mode == 2 ? (const unsigned*)(counter + 1) : nullptr;       // (the slot's second qword: the count)
                 const unsigned threshold = (unsigned)(d.n_blocks - d.n_blocks / 10);            // "nearly every block": 90 %
                 if (mode == 2) {
@@ -913,8 +956,11 @@ struct RowPool {
     unsigned want_threads()
     {
         if (knob(kKnobHostThreads) > 0) return (unsigned)knob(kKnobHostThreads);
-        unsigned t = std::thread::hardware_concurrency() / 4;
-        return t < 8 ? 8 : (t > 64 ? 64 : t);
+        // a quarter of the hardware threads, at least 8 where the host has them, at most 64 -- and never more than the host has
+        const unsigned hc = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1u;
+        unsigned t = hc / 4;
+        t = t < 8 ? 8 : (t > 64 ? 64 : t);
+        return t > hc ? hc : t;
     }
     // queues the job and returns at once; wait() (which also works on it) before anything it touches is reused
     std::shared_ptr<RowJob> submit(int64_t n, std::function<void(int64_t)> f, bool urgent)
@@ -1297,10 +1343,29 @@ int lz4hip_release_workspaces(void)
             g_fast_slab[dev].release();
             w.busy = false;
         }
+        if (pool == g_hc_ws && g_hc_pipe[dev].ready) {               // (the sub-chunk pipeline's streams and events hang off the LZ4HC lease)
+            if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
+            g_hc_pipe[dev].release();
+        }
         if (!w.p) continue;
         if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
         HIP_TRY(hipFree(w.p));
         w.p = nullptr; w.cap = 0; w.busy = false;
+    }
+    {
+        // the persistent lane decoder's counter ring: every slot's last user must be done (slot by slot, under the slot's lock)
+        CounterRing& r = g_counter_ring[dev];
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (r.mem) {
+            for (CounterSlot& cs : r.slot) {
+                std::lock_guard<std::mutex> sl(cs.mu);
+                if (cs.used && cs.done) HIP_TRY(hipEventSynchronize(cs.done));
+                if (cs.done) { (void)hipEventDestroy(cs.done); cs.done = nullptr; }
+                cs.used = false;
+            }
+            HIP_TRY(hipFree(r.mem));
+            r.mem = nullptr;
+        }
     }
     // ... and the CALLING thread's host-pointer staging for this device (device images + pinned slots; the host-pointer
     // entry points are synchronous, so nothing of this thread's is in flight here)

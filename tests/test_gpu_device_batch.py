@@ -55,6 +55,28 @@ def test_device_roundtrip_sampled_against_oracle(torch_cuda, oracle, dist, hc, d
         assert lens[i] == len(want) and np.array_equal(got, want), (dist, hc, i)
 
 
+def _full_size(torch, want, bytes_per_block):
+    """Blocks for a test that claims BASELINE.json's full batch size: everything earlier tests left behind is given back first
+    (torch's cached blocks, the library's table slabs and staging), and on a device with the MI355X's memory (>= 256 GB) the
+    full size is ASSERTED, not silently halved (the reference's bar is the whole corpus: src/LZ4.Tests/ConformanceTests.cs:121-133).
+    A smaller device still runs the test at the largest size that fits and says so."""
+    import gc
+    from lz4net_amd import _lib
+    gc.collect()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().lz4hip_release_workspaces())
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    n = want
+    while n * bytes_per_block * 1.05 > free and n > 1024:
+        n //= 2
+    if total >= 256 * 10**9:
+        assert n == want, f"{free / 2**30:.1f} GiB free of {total / 2**30:.1f}: the full-size test would shrink to {n} blocks"
+    elif n != want:
+        print(f"full-size test reduced to {n} of {want} blocks: device has {total / 2**30:.1f} GiB")
+    return n
+
+
 @pytest.mark.parametrize("dist", [2, 3], ids=["D2-fuzzer", "D3-records"])
 def test_full_size_decode_properties(torch_cuda, oracle, dist):
     """BASELINE config 2 shape (2^20 x 64 KiB, reduced only if the box has less memory): round trip is the
@@ -63,10 +85,7 @@ def test_full_size_decode_properties(torch_cuda, oracle, dist):
     encoders' repeat handling is exercised hardest)."""
     torch = torch_cuda
     from lz4net_amd import batch
-    free, _ = torch.cuda.mem_get_info()
-    n = 1 << 20
-    while n * (2 * batch.BLOCK + batch.BOUND_STRIDE) * 1.05 > free and n > 1024:
-        n //= 2
+    n = _full_size(torch, 1 << 20, 2 * batch.BLOCK + batch.BOUND_STRIDE)
     raw = batch.synth(dist, 7, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
     clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
@@ -158,6 +177,50 @@ def test_lane_decoder_persistent_many_restarts(torch_cuda, oracle):
         assert np.array_equal(back.cpu().numpy(), back_h)
 
 
+def test_lane_decoder_counter_slots_reused_across_streams(torch_cuda, oracle):
+    """The persistent lane decoder's work counters live in a per-device ring of 64 slots; a slot is handed out again after 64
+    further launches, on whatever stream.  One long persistent decode on stream A, then 80 short ones spread over eight other
+    streams while A is still running: the launch that draws A's slot again must wait for A (the slot's event) instead of zeroing
+    a counter A's lanes are still pulling from -- else its own lanes would draw numbers from A's range and decode nothing.
+    Every block of every launch is checked."""
+    torch = torch_cuda
+    from lz4net_amd import batch, _lib
+    n_big = 1 << 17
+    free, _ = torch.cuda.mem_get_info()
+    while n_big * (2 * batch.BLOCK + batch.BOUND_STRIDE) * 1.1 > free and n_big > 4096:
+        n_big //= 2
+    raw = batch.synth(2, 515, 0, n_big)
+    comp = torch.empty((n_big, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+    clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND)
+    back = torch.full_like(raw, 0x3C)
+    used = torch.zeros(n_big, dtype=torch.int32, device="cuda")
+    # the short launches: 256 blocks of 2 KiB each, their own buffers per launch
+    m, length, launches = 256, 2048, 80
+    small_raw = batch.synth(2, 516, 0, m * launches, length)
+    cap = length + length // 255 + 16
+    small_comp = torch.zeros((m * launches, cap + 8), dtype=torch.uint8, device="cuda")
+    small_len = batch.encode(small_raw, length, small_comp, cap)
+    small_back = torch.full_like(small_raw, 0x3C)
+    small_used = torch.zeros(m * launches, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(9)]
+    with ForcedMapping("LZ4HIP_DECODER", "lane"), _lib.tuning(decoder_persist=1):
+        with torch.cuda.stream(streams[0]):
+            batch.decode(comp, clen, back, batch.BLOCK, result=used)
+        for k in range(launches):
+            sl = slice(k * m, (k + 1) * m)
+            with torch.cuda.stream(streams[1 + k % 8]):
+                batch.decode(small_comp[sl], small_len[sl], small_back[sl], length, result=small_used[sl])
+        torch.cuda.synchronize()
+    assert bool((used == clen).all()) and batch.count_mismatches(raw, back, batch.BLOCK) == 0
+    assert bool((small_used == small_len).all()), "a short launch lost blocks: its counter slot was still in use"
+    assert batch.count_mismatches(small_raw, small_back, length) == 0
+    _lib.check(_lib.lib().lz4hip_release_workspaces())      # (frees the ring, its events included; the next launch builds a new one)
+    with ForcedMapping("LZ4HIP_DECODER", "lane"), _lib.tuning(decoder_persist=1):
+        batch.decode(small_comp[:m], small_len[:m], small_back[:m].fill_(0), length, result=small_used[:m].zero_())
+    assert bool((small_used[:m] == small_len[:m]).all()) and batch.count_mismatches(small_raw[:m], small_back[:m], length) == 0
+
+
 def _compare_whole_corpus(oracle, batch, comp, clen, hc, dist, seed, budget=240.0):
     """EVERY block's (compressed length, checksum of the compressed bytes) from the GPU rows against the CPU codec, which
     regenerates the block from its seed, compresses it and keeps only those two numbers (oracle/batch.c
@@ -186,10 +249,7 @@ def test_full_size_hc_encode_whole_corpus(torch_cuda, oracle, dist):
     (length + checksum for all of them, bytes for the sample), and the batch round-trips -- D2 and D3."""
     torch = torch_cuda
     from lz4net_amd import batch
-    free, _ = torch.cuda.mem_get_info()
-    n = 1 << 18
-    while n * (2 * batch.BLOCK + batch.BOUND_STRIDE + 200000) * 1.05 > free and n > 1024:
-        n //= 2
+    n = _full_size(torch, 1 << 18, 2 * batch.BLOCK + batch.BOUND_STRIDE + 200000)
     raw = batch.synth(dist, 11, 0, n)
     comp = torch.empty((n, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
     clen = batch.encode(raw, batch.BLOCK, comp, batch.BOUND, hc=True)

@@ -104,7 +104,7 @@ def test_limited_output(gpu, oracle, encoder, hc_mapping):
 
 @pytest.fixture(params=["wave", "lane"])
 def decoder(request):
-    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane.hpp).  The override
+    """Both block->hardware mappings of the decoder (lz4hip_decode.hpp / lz4hip_decode_lane4.hpp).  The override
     holds for every batch size, and the fixture asserts through lz4hip_dispatch_counts that the mapping named ran
     and the other one did not."""
     yield from _forced_fixture("LZ4HIP_DECODER", request.param)
@@ -388,6 +388,21 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
         if w >= 0 and not holes[i]:
             assert np.array_equal(dst[i, :w], out[:w]), ("unknown", i)
         assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)
+
+
+def test_decoder_fuzz_slice(gpu, oracle):
+    """A 30-second slice of tools/fuzz_gpu_decoders.py in every -m gpu run (tests/decoder_fuzz.py): arbitrary streams x known / unknown
+    output size x the three decoder forms -- wavefront mapping with bursts, lane mapping, the persistent lane grid with ONE wavefront
+    (every lane restarts with its predecessor's loads still in flight) -- against the CPU oracle: results, bytes, canaries.  The
+    seeds move with the day so that successive runs cover different streams; a failure prints the seed."""
+    import time
+    import decoder_fuzz
+    msgs = []
+    first = 2000 + int(time.time() // 86400) % 1000 * 16
+    total, bad, done = decoder_fuzz.run(oracle, first, 16, 240, seconds=30.0, report=msgs.append)
+    print(f"decoder fuzz slice: seeds {first}..{first + done - 1}, {total} comparisons, {bad} mismatches")
+    assert bad == 0, msgs[:10]
+    assert total >= 3 * 270 * 2 * 3
 
 
 def test_release_workspaces_then_reuse(gpu, oracle):
