@@ -147,6 +147,12 @@ class Workload:
                              for _ in range(2))
         self.comp_bytes = int(self.clen.to(torch.int64).sum().item())
         assert bool((self.clen > 0).all()), "encoder reported failure on a block"
+        # what the lane encoder's table slab measured when the library built it (the line must say which
+        # placement the encoder ran on): G probe steps per second, candidates built, chunks of the one in use
+        from lz4net_amd import _lib
+        self.slab = {"encoder_slab_rate_Gsteps": _lib.tuning_get("encoder_slab_rate") / 1000.0,
+                     "encoder_slab_tried": _lib.tuning_get("encoder_slab_tried"),
+                     "encoder_slab_chunks": _lib.tuning_get("encoder_slab_chunks")}
 
     def decode_step(self):
         self.batch.decode(self.comp, self.clen, self.back, self.batch.BLOCK, known_output_size=True, result=self.used)
@@ -368,7 +374,7 @@ def main():
     }
     extras[DIST_NAMES[args.dist]] = head
     alg_bytes_local, mean_kernel_ms = wl.algorithmic_bytes, sum(kernel_ms) / len(kernel_ms)
-    enc_roof = {"ms": wl.encode_ms, "alg": wl.algorithmic_bytes, "blocks": n}      # BASELINE configs[2]
+    enc_roof = {"ms": wl.encode_ms, "alg": wl.algorithmic_bytes, "blocks": n, "slab": wl.slab}      # BASELINE configs[2]
     hc_roof = None                                                               # BASELINE configs[3]
     if world == 1 and not args.no_extras and not args.hc_only and args.decoder == "auto":
         for name in ("lane", "wave"):
@@ -519,14 +525,32 @@ def main():
                     dt = time.perf_counter() - t1
                     t_host = dt if t_host is None else min(t_host, dt)
                 ok_h = bool((res_h == clen_h).all()) and bool(np.array_equal(back_h, raw_h))
-                return round(m * batch.BLOCK / t_host / 1e9, 2), ok_h
+                # ... and the encode side of the same entry points: what a caller shaped like LZ4Stream.FlushCurrentChunk
+                # (reference src/LZ4/LZ4Stream.cs:239-269) gets -- pageable rows in, compressed rows out
+                enc_h = np.zeros_like(comp_h)
+                ecap_h = np.full(m, batch.BOUND, np.int32)
+                elen_h = np.full(m, batch.BLOCK, np.int32)
+                eres_h = np.zeros(m, np.int32)
+                eb = _lib.Batch(src=raw_h.ctypes.data, src_off=None, src_stride=raw_h.strides[0], src_len=elen_h.ctypes.data,
+                                dst=enc_h.ctypes.data, dst_off=None, dst_stride=enc_h.strides[0], dst_cap=ecap_h.ctypes.data,
+                                dst_cap_all=0, src_len_all=batch.BLOCK, result=eres_h.ctypes.data, n_blocks=m)
+                _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(eb), 0))
+                t_enc = None
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(eb), 0))
+                    dt = time.perf_counter() - t1
+                    t_enc = dt if t_enc is None else min(t_enc, dt)
+                ok_e = bool((eres_h == clen_h).all()) and all(np.array_equal(enc_h[i, :clen_h[i]], comp_h[i, :clen_h[i]]) for i in range(0, m, max(m // 256, 1)))
+                return round(m * batch.BLOCK / t_host / 1e9, 2), ok_h, round(m * batch.BLOCK / t_enc / 1e9, 2), ok_e
 
             m_big, m_small = min(16384, n), min(4096, n)
-            rate_big, ok_big = host_decode_rate(m_big)
-            rate_small, ok_small = host_decode_rate(m_small)
+            rate_big, ok_big, erate_big, eok_big = host_decode_rate(m_big)
+            rate_small, ok_small, erate_small, eok_small = host_decode_rate(m_small)
             extras["host_pointer_batch_pcie_inclusive"] = {
                 "decode_GBps": rate_big, "blocks": m_big, "decode_GBps_small_batch": rate_small, "blocks_small_batch": m_small,
-                "ok": ok_big and ok_small,
+                "encode_fast_GBps": erate_big, "encode_fast_GBps_small_batch": erate_small,
+                "ok": ok_big and ok_small and eok_big and eok_small,
                 "note": "lz4hip_decode_batch_host on pageable host arrays: gather + H2D + kernels + D2H + scatter, best of 3 "
                         "(reported beside, never as, `value`); a batch is cut into 1-6 slices (one per ~2048 blocks) whose copies and kernels overlap",
             }
@@ -564,6 +588,7 @@ def main():
                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": r["alg"], "kernel_ms": round(r["ms"], 3), "blocks": r["blocks"],
                 "uncompressed_GBps": round(r["blocks"] * batch.BLOCK / (r["ms"] / 1e3) / 1e9, 2),
+                **(r.get("slab") or {}),
                 "bit_exact_vs_cpu_reference": check}
 
     line = {

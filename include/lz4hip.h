@@ -150,7 +150,8 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 when the slab is built (first large batch on a device) the library times a probe kernel on it and, if the placement
  *                                 is slower than a well spread one, builds up to this many candidates and keeps the fastest (0 = default 4;
  *                                 1 = the first candidate, unmeasured).  Read-only through lz4hip_tuning_get: "encoder_slab_rate" (what the
- *                                 current device's slab measured, 1000 x G probe steps per second; 0 = none / unmeasured), "encoder_slab_tried"
+ *                                 current device's slab measured, 1000 x G probe steps per second; 0 = none / unmeasured), "encoder_slab_tried" (candidates built),
+ *                                 "encoder_slab_chunks" (separate allocations the slab in use consists of)
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

@@ -88,8 +88,8 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
 constexpr int64_t kLaneEncodeMinBlocks = 16384;
 constexpr int kLaneDecodeGeneration = 4;
-constexpr int kLane4Config = 27192;          // generation 4: 192-byte ring, 32-byte input pieces, 128-byte flush units; iterations alternate between
-                                              // flushing (two store instructions) and requesting input (two load instructions)
+constexpr int kLane4Config = 59192;          // lane decoder: 192-byte ring, 32-byte input pieces out of whole 64-byte sectors, 128-byte flush units; iterations
+                                              // alternate between flushing (two store instructions) and requesting input (four load instructions, one sector)
 constexpr int64_t kHcHostSliceBlocks = 16384;  // host-pointer LZ4HC batches: blocks per slice
 constexpr int kHcLaneGeneration = 4;           // blocks <= 64 KiB; larger ones: 2
 
@@ -676,14 +676,15 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
         if (gen == 4) {
             // decoder_ring = ring bytes + 1000 x variant (variant bit 0: 128-byte flush units, bit 1: 32-byte input pieces,
             // bit 2: one flush store instruction per iteration, bit 3: the flush runs in every second iteration only,
-            // bit 4: input pieces are requested in the other iterations only)
+            // bit 4: input pieces are requested in the other iterations only, bit 5: sector input -- L holds a whole 64-byte sector
+            // of the source and feeds the window one 32-byte half at a time)
             const int cfg = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane4Config;
-#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS, FE, IE)                                                                         \
+#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS, FE, IE, POL)                                                                    \
             do {                                                                                                                \
-                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS, FE, IE>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
-                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS, FE, IE>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+                if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS, FE, IE, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
+                else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS, FE, IE, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
             } while (0)
-#define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2, ((CFG) / 1000 & 8) ? 2 : 1, ((CFG) / 1000 & 16) ? 2 : 1); break
+#define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2, ((CFG) / 1000 & 8) ? 2 : 1, ((CFG) / 1000 & 16) ? 2 : 1, ((CFG) / 1000 & 32) ? 16 : 0); break
             // Default configuration: TWO forms of the same kernel.  One block per lane under hardware dispatch is the faster one for
             // a large batch whose blocks all take the lane mapping (2^20 D2 blocks: 980 vs 952 GB/s); the persistent grid, whose lanes pull
             // blocks from a counter and skip what the filter does not select, wins when a wavefront would idle otherwise -- a batch of
@@ -694,14 +695,15 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             const int persist = knob(kKnobDecoderPersist);
             if (cfg == kLane4Config && persist != 2) {
                 constexpr int R_ = kLane4Config % 1000, P_ = (kLane4Config / 1000 & 2) ? 32 : 64, FU_ = (kLane4Config / 1000 & 1) ? 128 : 64,
-                              FS_ = (kLane4Config / 1000 & 4) ? 1 : 2, FE_ = (kLane4Config / 1000 & 8) ? 2 : 1, IE_ = (kLane4Config / 1000 & 16) ? 2 : 1;
+                              FS_ = (kLane4Config / 1000 & 4) ? 1 : 2, FE_ = (kLane4Config / 1000 & 8) ? 2 : 1, IE_ = (kLane4Config / 1000 & 16) ? 2 : 1,
+                              POL_ = (kLane4Config / 1000 & 32) ? 16 : 0;
                 int dev = 0, cus = 0;
                 HIP_TRY(hipGetDevice(&dev));
                 HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                 static std::atomic<int> per_cu_cached[64];
                 int per_cu = dev >= 0 && dev < 64 ? per_cu_cached[dev].load(std::memory_order_relaxed) : 0;
                 if (per_cu <= 0) {
-                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_>, 64, 0));
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POL_>, 64, 0));
                     if (per_cu <= 0) per_cu = 1;
                     if (dev >= 0 && dev < 64) per_cu_cached[dev].store(per_cu, std::memory_order_relaxed);
                 }
@@ -720,15 +722,15 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                     HIP_TRY(hipGetLastError());
                 }
                 if (mode != 1) {
-                    if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
-                    else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                    if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                    else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
                     HIP_TRY(hipGetLastError());
                 }
                 if (mode != 0) {
                     unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
                     if (knob(kKnobDecoderGroups) > 0 && (unsigned)knob(kKnobDecoderGroups) < pg) pg = (unsigned)knob(kKnobDecoderGroups);
-                    if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
-                    else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                    if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                    else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
                 }
             } else
             switch (cfg) {
@@ -736,6 +738,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
 #ifdef LZ4HIP_TUNING_BUILD                                              /* residency / ring / piece / flush-unit sweeps (tools/ab_decoder_knobs.py) */
             LZ4HIP_LANE4_CASE(128); LZ4HIP_LANE4_CASE(2128); LZ4HIP_LANE4_CASE(6128); LZ4HIP_LANE4_CASE(3192); LZ4HIP_LANE4_CASE(192); LZ4HIP_LANE4_CASE(1192); LZ4HIP_LANE4_CASE(2192);
             LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(7192); LZ4HIP_LANE4_CASE(11192); LZ4HIP_LANE4_CASE(25192); LZ4HIP_LANE4_CASE(11256); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
+            LZ4HIP_LANE4_CASE(27192); LZ4HIP_LANE4_CASE(43192); LZ4HIP_LANE4_CASE(35192); LZ4HIP_LANE4_CASE(58128); LZ4HIP_LANE4_CASE(59256); LZ4HIP_LANE4_CASE(59224); LZ4HIP_LANE4_CASE(59208);
 #endif
             default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
             }
@@ -1404,11 +1407,11 @@ int lz4hip_tuning_get(const char* name)
     knobs_init();
     // read-only: what the placement of the current device's lane-encoder slab measured, in M steps per second (0: no slab yet or not measured),
     // and how many candidate placements were built
-    if (name && (strcmp(name, "encoder_slab_rate") == 0 || strcmp(name, "encoder_slab_tried") == 0)) {
+    if (name && (strcmp(name, "encoder_slab_rate") == 0 || strcmp(name, "encoder_slab_tried") == 0 || strcmp(name, "encoder_slab_chunks") == 0)) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
         std::lock_guard<std::mutex> lk(g_fast_ws[dev].mu);
-        return name[13] == 'r' ? (int)(g_fast_slab[dev].probe * 1000.0) : g_fast_slab[dev].tries;
+        return name[13] == 'r' ? (int)(g_fast_slab[dev].probe * 1000.0) : (name[13] == 't' ? g_fast_slab[dev].tries : (int)g_fast_slab[dev].chunks.size());
     }
     for (int k = 0; name && k < kKnobCount; k++)
         if (strcmp(name, kKnobInfo[k].name) == 0) return g_knob[k].load(std::memory_order_relaxed);

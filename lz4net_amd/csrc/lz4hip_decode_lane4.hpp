@@ -39,6 +39,9 @@ namespace lz4hip {
 #ifndef LZ4HIP_DEC4_FLUSH_RECS
 #define LZ4HIP_DEC4_FLUSH_RECS 0      /* 0 = all the two store instructions can carry; the emulator's 'starved' build: 4 */
 #endif
+#ifndef LZ4HIP_DEC4_DUAL_STORE
+#define LZ4HIP_DEC4_DUAL_STORE 2      /* 1, 2: a ring store is issued at `row` and at `row - ring size`, the hardware drops the one outside the allocation (2: two rows per LDS instruction); 0: the row is wrapped */
+#endif
 constexpr unsigned lane4_lds_bytes(int ring_bytes) { return 64u * (unsigned)ring_bytes + 16u * 32u; }
 
 // What a lane does when its block is finished.  NoNext: nothing (one block per lane, the wavefront ends when its last lane does).
@@ -58,7 +61,10 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //   FS     flush store instructions per flushing iteration (1 or 2): each carries 64 / (FU / 16) units
 //   FE     the flush runs in every FE-th iteration (1 or 2)
 //   IE     2: the next input piece is only requested in the iterations that do not flush (needs FE == 2); 1: in every iteration
-//   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces
+//   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces;
+//          bit 4 (16): SECTOR INPUT -- L holds a whole aligned 64-byte sector (four loads, one request to the memory side) and feeds
+//          W one 32-byte half at a time (needs P == 32): the window and its select tree stay those of 32-byte pieces, but each
+//          sector of the source is fetched once instead of as two halves ~10 us apart (by then the first one's line has left the L2)
 template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0, class NEXT = NoNext>
 LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* src, int iend,
                                      uint8_t* dst, int oend, NEXT next = NEXT())
@@ -72,7 +78,11 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     constexpr int RW = R / 4;                                        // ring rows (one dword per lane per row)
     constexpr bool RPOW2 = (RW & (RW - 1)) == 0;
     constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
-    constexpr int NW = 4 + P / 4, NL = P / 16;                       // window dwords, loads per piece
+    constexpr uint32_t kLdsBytes = lane4_lds_bytes(R);
+    constexpr bool LS = (POL & 16) != 0;                             // L = one aligned 64-byte sector, consumed as two pieces
+    static_assert(!LS || P == 32, "sector input feeds 32-byte pieces");
+    constexpr int SK = LS ? 64 : P;                                  // alignment of the stream coordinates (what the loads are aligned to)
+    constexpr int NW = 4 + P / 4, NL = LS ? 4 : P / 16;              // window dwords, loads per request
     constexpr int HPR = FU / 16, RECS_PER_STORE = 64 / HPR;          // helper lanes per flush record, records per store instruction
     constexpr int kFlushRecs = (LZ4HIP_DEC4_FLUSH_RECS) ? (LZ4HIP_DEC4_FLUSH_RECS) : FS * RECS_PER_STORE;
     constexpr bool kLineNoWrap = R % 64 == 0;                        // a 64-byte line of the ring (16 rows from a multiple of 16) never wraps inside
@@ -114,6 +124,9 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     int final_seen = 0, final_run = 0, result = 0, done = 0;
     int exhausted = 0;           // (persistent kernels) this lane has no further block
     wv::u32x4 fa = { 0, 0, 0, 0 }, fb = { 0, 0, 0, 0 };
+#if defined(LZ4HIP_DEC4_BALLAST_VALU) || defined(LZ4HIP_DEC4_BALLAST_LDS)
+    uint32_t ballast = 0;
+#endif
 #pragma unroll
     for (int j = 0; j < NW; j++) W[j] = 0;
 #pragma unroll
@@ -123,7 +136,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     // piece -- no loads here, so a lane of a persistent kernel can restart while its wavefront's accesses are in flight (a piece of the
     // finished block that lands in L afterwards is overwritten by the new block's piece 0, which was issued later: loads return in order).
     auto start_block = [&](bool act) {
-        skew = (int)((uint64_t)src & (uint64_t)(P - 1));
+        skew = (int)((uint64_t)src & (uint64_t)(SK - 1));
         src_al = (uint64_t)src - (uint64_t)skew;
         in_total = iend > 0 ? (int)(((int64_t)skew + iend + P - 1) & ~(int64_t)(P - 1)) : 0;
         out_limit = oend > kLastLiterals ? (uint32_t)(oend - kLastLiterals) : 0u;
@@ -137,19 +150,48 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 
     // Append the low n_ bytes of the data dwords at op: rotated to the byte phase of op (one v_perm_b32 per dword), the
     // first dword merged into the ring under a byte mask, the others stored whole.
+#define L4_STORE2(OFF_, v_) do { const uint32_t w_ = (v_); wv::lds_store_drop<OFF_>(lds, kLdsBytes, oa, w_); wv::lds_store_drop<OFF_>(lds, kLdsBytes, ob_, w_); } while (0)
 #define L4_APPEND(d0_, d1_, d2_, d3_, n_, FOUR_)                                                         \
     do {                                                                                                \
         const uint32_t sb_ = (uint32_t)op & 3u;                                                         \
         const uint32_t s_ = wv::alignbyte(0x08070605u, 0x04030201u, sb_ ^ 3u);                          \
-        const uint32_t a1_ = ring_add(oa, 256u), a2_ = ring_add(oa, 512u), a3_ = ring_add(oa, 768u);    \
         wv::lds_mskor(&L4_RING(oa), 0xFFFFFFFFu << (8u * sb_), wv::perm(d0_, 0u, s_));                  \
-        L4_RING(a1_) = wv::perm(d1_, d0_, s_);                                                          \
-        L4_RING(a2_) = wv::perm(d2_, d1_, s_);                                                          \
-        if (FOUR_) {                                                                                    \
-            L4_RING(a3_) = wv::perm(d3_, d2_, s_);                                                      \
-            L4_RING(ring_add(oa, 1024u)) = wv::perm(0u, d3_, s_);                                       \
+        if (LZ4HIP_DEC4_DUAL_STORE) {                                                                   \
+            /* rows oa + 1 .. oa + 4, not wrapped: the rows past the end of the ring land in the flush records (rewritten before \
+               they are next read) or outside the allocation (dropped), and the same rows seen from one ring size below land \
+               where they belong or below address 0 (dropped) */                                        \
+            const uint32_t ob_ = oa - kRingBytes;                                                       \
+            const uint32_t w1_ = wv::perm(d1_, d0_, s_), w2_ = wv::perm(d2_, d1_, s_);                  \
+            if (LZ4HIP_DEC4_DUAL_STORE == 2) { /* two rows per LDS instruction */                       \
+                wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, oa, w1_, w2_);                           \
+                wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, ob_, w1_, w2_);                          \
+                if (FOUR_) {                                                                            \
+                    const uint32_t w3_ = wv::perm(d3_, d2_, s_), w4_ = wv::perm(0u, d3_, s_);           \
+                    wv::lds_store2_rows_drop<3, 4>(lds, kLdsBytes, oa, w3_, w4_);                       \
+                    wv::lds_store2_rows_drop<3, 4>(lds, kLdsBytes, ob_, w3_, w4_);                      \
+                } else {                                                                                \
+                    L4_STORE2(768, wv::perm(0u, d2_, s_));                                              \
+                }                                                                                       \
+            } else {                                                                                    \
+                L4_STORE2(256, w1_);                                                                    \
+                L4_STORE2(512, w2_);                                                                    \
+                if (FOUR_) {                                                                            \
+                    L4_STORE2(768, wv::perm(d3_, d2_, s_));                                             \
+                    L4_STORE2(1024, wv::perm(0u, d3_, s_));                                             \
+                } else {                                                                                \
+                    L4_STORE2(768, wv::perm(0u, d2_, s_));                                              \
+                }                                                                                       \
+            }                                                                                           \
         } else {                                                                                        \
-            L4_RING(a3_) = wv::perm(0u, d2_, s_);                                                       \
+            const uint32_t a1_ = ring_add(oa, 256u), a2_ = ring_add(oa, 512u), a3_ = ring_add(oa, 768u); \
+            L4_RING(a1_) = wv::perm(d1_, d0_, s_);                                                      \
+            L4_RING(a2_) = wv::perm(d2_, d1_, s_);                                                      \
+            if (FOUR_) {                                                                                \
+                L4_RING(a3_) = wv::perm(d3_, d2_, s_);                                                  \
+                L4_RING(ring_add(oa, 1024u)) = wv::perm(0u, d3_, s_);                                   \
+            } else {                                                                                    \
+                L4_RING(a3_) = wv::perm(0u, d2_, s_);                                                   \
+            }                                                                                           \
         }                                                                                               \
         oa = ring_add(oa, ((sb_ + (uint32_t)(n_)) << 6) & 0x700u);                                      \
         op += (n_);                                                                                     \
@@ -172,14 +214,26 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             const wv::mask_t cm = wv::cond(d >= P) & (wv::cond(lvalid != 0) | wv::cond(no_more));   // (lane masks combined by scalar instructions)
 #pragma unroll
             for (int j = 0; j < 4; j++) W[j] = wv::sel(cm, W[P / 4 + j], W[j]);
+            if constexpr (LS) {
+                // the piece at wb + 16 + P is the low or the high half of the sector in L; after the low half L stays valid
+                const bool hi_half = ((wb + 16 + P) & 32) != 0;
+                const wv::mask_t hm = wv::cond(((wb + 16 + P) & 32) != 0);
 #pragma unroll
-            for (int j = 0; j < NL; j++) {
-                W[4 + 4 * j] = wv::sel(cm, L[j].x, W[4 + 4 * j]); W[5 + 4 * j] = wv::sel(cm, L[j].y, W[5 + 4 * j]);
-                W[6 + 4 * j] = wv::sel(cm, L[j].z, W[6 + 4 * j]); W[7 + 4 * j] = wv::sel(cm, L[j].w, W[7 + 4 * j]);
+                for (int j = 0; j < 2; j++) {
+                    W[4 + 4 * j] = wv::sel(cm, wv::sel(hm, L[2 + j].x, L[j].x), W[4 + 4 * j]); W[5 + 4 * j] = wv::sel(cm, wv::sel(hm, L[2 + j].y, L[j].y), W[5 + 4 * j]);
+                    W[6 + 4 * j] = wv::sel(cm, wv::sel(hm, L[2 + j].z, L[j].z), W[6 + 4 * j]); W[7 + 4 * j] = wv::sel(cm, wv::sel(hm, L[2 + j].w, L[j].w), W[7 + 4 * j]);
+                }
+                lvalid = (cross & hi_half) ? 0 : lvalid;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NL; j++) {
+                    W[4 + 4 * j] = wv::sel(cm, L[j].x, W[4 + 4 * j]); W[5 + 4 * j] = wv::sel(cm, L[j].y, W[5 + 4 * j]);
+                    W[6 + 4 * j] = wv::sel(cm, L[j].z, W[6 + 4 * j]); W[7 + 4 * j] = wv::sel(cm, L[j].w, W[7 + 4 * j]);
+                }
+                lvalid = cross ? 0 : lvalid;
             }
             wb += cross ? P : 0;
             d -= cross ? P : 0;
-            lvalid = cross ? 0 : lvalid;
         }
         const bool staged16 = d < P;                                 // the 16 bytes at the cursor lie in W (what lies past the source is never used)
         LZ4HIP_STAT(0, true); LZ4HIP_STAT(1, done == 0); LZ4HIP_STAT(2, (done == 0) & !staged16);
@@ -387,11 +441,15 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 
         // ---- (T6) the next piece of input, once L is free: ALWAYS NL load instructions, each lane for itself ----
         if constexpr (INPUT) {
-            const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for
+            const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for (sector input: a multiple of 64 whenever L is free)
             const wv::mask_t req = wv::cond((done | lvalid | us_pend) == 0) & wv::cond(lpos < in_total);
             const uint64_t g = src_al + (uint64_t)(uint32_t)lpos;
-#pragma unroll
-            for (int j = 0; j < NL; j++) wv::vm_load16_mask<(POL >> 2) & 3>(req, g + 16u * (unsigned)j, L[j]);
+            wv::vm_load16_mask_off<(POL >> 2) & 3, 0>(req, g, L[0]);
+            wv::vm_load16_mask_off<(POL >> 2) & 3, 16>(req, g, L[1]);
+            if constexpr (NL == 4) {
+                wv::vm_load16_mask_off<(POL >> 2) & 3, 32>(req, g, L[2]);
+                wv::vm_load16_mask_off<(POL >> 2) & 3, 48>(req, g, L[3]);
+            }
             ld_pend = (int)wv::sel(req, 1u, 0u);
         } else {
             ld_pend = 0;
@@ -403,6 +461,17 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         lvalid = us_pend ? 1 : lvalid;
         us_pend = 0;
 
+#if defined(LZ4HIP_DEC4_BALLAST_VALU) || defined(LZ4HIP_DEC4_BALLAST_LDS)
+        // (diagnostic builds only, tools/r04/call16.sh: what does the iteration rate do with N more vector-ALU / LDS instructions?)
+#ifdef LZ4HIP_DEC4_BALLAST_VALU
+#pragma unroll
+        for (int bi = 0; bi < LZ4HIP_DEC4_BALLAST_VALU; bi++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(ballast) : "v"(lane4));
+#endif
+#ifdef LZ4HIP_DEC4_BALLAST_LDS
+#pragma unroll
+        for (int bi = 0; bi < LZ4HIP_DEC4_BALLAST_LDS; bi++) wv::lds_store_drop<0>(lds, kLdsBytes, 0x80000000u + lane4, ballast);
+#endif
+#endif
         // ---- (B3) append the chunk ----
         {
             const bool far_src = kind == kK4Far;
@@ -478,6 +547,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
 #undef L4_RING
 #undef L4_PHASE_SEL
 #undef L4_APPEND
+#undef L4_STORE2
 }
 
 // How many blocks of the batch the filter selects (one launch in front of a large partitioned batch): the two lane kernels below

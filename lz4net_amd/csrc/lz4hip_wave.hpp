@@ -218,6 +218,22 @@ LZ4HIP_DEVICE void vm_load16_mask(mask_t mk, uint64_t addr, u32x4& v)
     else LZ4HIP_VM_LOAD("");
 #undef LZ4HIP_VM_LOAD
 }
+// ... with a constant byte offset in the instruction's offset field (0 .. 4095): the loads of one piece share one address pair
+template <int POLICY, int OFF>
+LZ4HIP_DEVICE void vm_load16_mask_off(mask_t mk, uint64_t addr, u32x4& v)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "global_load offset field");
+    const uint64_t m = mk.v;
+    uint64_t saved;
+#define LZ4HIP_VM_LOAD(MODS)                                                                                                                      \
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[a], off offset:%[o]" MODS "\n\ts_mov_b64 exec, %[sv]"       \
+                 : [d] "+v"(v), [sv] "=&s"(saved) : [a] "v"(addr), [m] "s"(m), [o] "n"(OFF) : "memory")
+    if (POLICY == 1) LZ4HIP_VM_LOAD(" nt");
+    else if (POLICY == 2) LZ4HIP_VM_LOAD(" sc1");
+    else if (POLICY == 3) LZ4HIP_VM_LOAD(" sc0 sc1");
+    else LZ4HIP_VM_LOAD("");
+#undef LZ4HIP_VM_LOAD
+}
 LZ4HIP_DEVICE void vm_store16_mask(mask_t mk, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     const uint64_t m = mk.v;
@@ -233,6 +249,35 @@ LZ4HIP_DEVICE void vm_store16_mask(mask_t mk, uint64_t addr, uint32_t a, uint32_
 LZ4HIP_DEVICE void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data)
 {
     asm volatile("ds_mskor_b32 %[a], %[m], %[d]" : : [a] "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p), [m] "v"(mask), [d] "v"(data) : "memory");
+}
+
+// DS_WRITE_B32 at lds + a + OFF where that address MAY LIE OUTSIDE the workgroup's LDS allocation of lds_bytes (a is a 32-bit value
+// that may have wrapped below zero): gfx950 drops such a store -- no fault, nothing outside the allocation changes
+// (tools/lds_out_of_range.hip, profiles/r04/lds_out_of_range.txt).  The lane decoder issues every ring store twice, at `row` and at
+// `row - ring size`, instead of wrapping the row address with three vector-ALU instructions.
+template <int OFF>
+LZ4HIP_DEVICE void lds_store_drop(unsigned char* lds, uint32_t lds_bytes, uint32_t a, uint32_t v)
+{
+    (void)lds_bytes;
+    asm volatile("ds_write_b32 %[a], %[v] offset:%[o]" : : [a] "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + a), [v] "v"(v), [o] "n"(OFF) : "memory");
+}
+// DS_WRITE2ST64_B32: two dwords in one instruction, at lds + a + 256 * ROW0 and lds + a + 256 * ROW1; each of the two addresses is checked
+// (and dropped) on its own.
+template <int ROW0, int ROW1>
+LZ4HIP_DEVICE void lds_store2_rows_drop(unsigned char* lds, uint32_t lds_bytes, uint32_t a, uint32_t v0, uint32_t v1)
+{
+    (void)lds_bytes;
+    asm volatile("ds_write2st64_b32 %[a], %[v0], %[v1] offset0:%[o0] offset1:%[o1]"
+                 : : [a] "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + a), [v0] "v"(v0), [v1] "v"(v1), [o0] "n"(ROW0), [o1] "n"(ROW1) : "memory");
+}
+// DS_READ_B32 under the same rule: an out-of-range load returns 0 (same evidence)
+template <int OFF>
+LZ4HIP_DEVICE uint32_t lds_load_zero(const unsigned char* lds, uint32_t lds_bytes, uint32_t a)
+{
+    (void)lds_bytes;
+    uint32_t r;
+    asm volatile("ds_read_b32 %[r], %[a] offset:%[o]" : [r] "=v"(r) : [a] "v"((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)lds + a), [o] "n"(OFF) : "memory");
+    return r;
 }
 
 LZ4HIP_DEVICE int ctz64(uint64_t m) { return __builtin_ctzll(m); }

@@ -71,7 +71,7 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     elif lane:
         lib().emu_decode_lane(*args, 0, lane, stage)
     elif auto:        # the library's default: the batch is partitioned between the two mappings
-        lib().emu_decode_lane4(*args, 2, 27192)
+        lib().emu_decode_lane4(*args, 2, 59192)
         lib().emu_decode(*args, waves_per_group, 1)
     else:
         lib().emu_decode(*args, waves_per_group, 0)

@@ -97,12 +97,12 @@ void emu_decode_lane4(int known, const uint8_t* src, int64_t src_stride, const i
     dim3 grid((unsigned)((n + 63) / 64)), block(64);
 #define EMU_LANE4(CFG)                                                                                                          \
     case CFG: {                                                                                                                 \
-        constexpr int R = (CFG) % 1000, P = ((CFG) / 1000 & 2) ? 32 : 64, FU = ((CFG) / 1000 & 1) ? 128 : 64, FS = ((CFG) / 1000 & 4) ? 1 : 2, FE = ((CFG) / 1000 & 8) ? 2 : 1, IE = ((CFG) / 1000 & 16) ? 2 : 1;  \
-        if (known) simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<true, R, P, FU, FS, FE, IE>(b, filter); });     \
-        else       simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<false, R, P, FU, FS, FE, IE>(b, filter); });    \
+        constexpr int R = (CFG) % 1000, P = ((CFG) / 1000 & 2) ? 32 : 64, FU = ((CFG) / 1000 & 1) ? 128 : 64, FS = ((CFG) / 1000 & 4) ? 1 : 2, FE = ((CFG) / 1000 & 8) ? 2 : 1, IE = ((CFG) / 1000 & 16) ? 2 : 1, POL = ((CFG) / 1000 & 32) ? 16 : 0;  \
+        if (known) simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<true, R, P, FU, FS, FE, IE, POL>(b, filter); });     \
+        else       simt::launch(grid, block, lane4_lds_bytes(R), [=] { decode_lane4_kernel<false, R, P, FU, FS, FE, IE, POL>(b, filter); });    \
     } break
     switch (cfg) {
-    EMU_LANE4(128); EMU_LANE4(2128); EMU_LANE4(192); EMU_LANE4(1192); EMU_LANE4(3192); EMU_LANE4(7192); EMU_LANE4(1256); EMU_LANE4(2240); EMU_LANE4(5256); EMU_LANE4(11192); EMU_LANE4(15192); EMU_LANE4(27192); EMU_LANE4(25192);
+    EMU_LANE4(128); EMU_LANE4(2128); EMU_LANE4(192); EMU_LANE4(1192); EMU_LANE4(3192); EMU_LANE4(7192); EMU_LANE4(1256); EMU_LANE4(2240); EMU_LANE4(5256); EMU_LANE4(11192); EMU_LANE4(15192); EMU_LANE4(27192); EMU_LANE4(25192); EMU_LANE4(59192); EMU_LANE4(35192); EMU_LANE4(34128);
     default: simt::die("emu_decode_lane4: configuration not instantiated", cfg, 0);
     }
 #undef EMU_LANE4
@@ -117,8 +117,8 @@ void emu_decode_lane4_persistent(int known, const uint8_t* src, int64_t src_stri
     counter = 0;
     unsigned long long* c = &counter;
     dim3 grid((unsigned)groups), block(64);
-    if (known) simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<true, 192, 32, 128, 2, 2, 2>(b, filter, c); });
-    else       simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<false, 192, 32, 128, 2, 2, 2>(b, filter, c); });
+    if (known) simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<true, 192, 32, 128, 2, 2, 2, 16>(b, filter, c); });
+    else       simt::launch(grid, block, lane4_lds_bytes(192), [=] { decode_lane4_persistent_kernel<false, 192, 32, 128, 2, 2, 2, 16>(b, filter, c); });
 }
 
 void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,

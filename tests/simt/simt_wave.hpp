@@ -192,7 +192,30 @@ inline bool any(mask_t m) { return any(m.v); }
 inline uint32_t sel(mask_t m, uint32_t a, uint32_t b) { return m.v ? a : b; }
 template <int POLICY = 0>
 inline void vm_load16_mask(mask_t m, uint64_t addr, u32x4& v) { vm_load16_pred<POLICY>(m.v, addr, v); }
+template <int POLICY, int OFF>
+inline void vm_load16_mask_off(mask_t m, uint64_t addr, u32x4& v) { vm_load16_pred<POLICY>(m.v, addr + (uint64_t)OFF, v); }
 inline void vm_store16_mask(mask_t m, uint64_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { vm_store16_pred(m.v, addr, a, b, c, d); }
+// (the hardware drops a store outside the workgroup's allocation and returns 0 for such a load; the address arithmetic is 32-bit)
+template <int OFF>
+inline void lds_store_drop(unsigned char* lds, uint32_t lds_bytes, uint32_t a, uint32_t v)
+{
+    const uint32_t t = a + (uint32_t)OFF;
+    if (t <= lds_bytes - 4u) std::memcpy(lds + t, &v, 4);
+}
+template <int ROW0, int ROW1>
+inline void lds_store2_rows_drop(unsigned char* lds, uint32_t lds_bytes, uint32_t a, uint32_t v0, uint32_t v1)
+{
+    lds_store_drop<256 * ROW0>(lds, lds_bytes, a, v0);
+    lds_store_drop<256 * ROW1>(lds, lds_bytes, a, v1);
+}
+template <int OFF>
+inline uint32_t lds_load_zero(const unsigned char* lds, uint32_t lds_bytes, uint32_t a)
+{
+    const uint32_t t = a + (uint32_t)OFF;
+    uint32_t r = 0;
+    if (t <= lds_bytes - 4u) std::memcpy(&r, lds + t, 4);
+    return r;
+}
 inline void lds_mskor(uint32_t* p, uint32_t mask, uint32_t data) { *p = (*p & ~mask) | data; }
 
 inline int ctz64(uint64_t m) { return __builtin_ctzll(m); }

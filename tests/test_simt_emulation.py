@@ -25,8 +25,8 @@ def _mapping(m):
     return {}
 
 
-LANE3 = ["l3r128", "l3r240", "l4c11192", "l4c27192", "l4p1", "l4p3"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
-LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128", "l4c128", "l4c2128", "l4c192", "l4c1192", "l4c3192", "l4c7192", "l4c1256", "l4c2240", "l4c5256", "l4c11192", "l4c15192", "l4c27192", "l4c25192"]
+LANE3 = ["l3r128", "l3r240", "l4c11192", "l4c27192", "l4c59192", "l4p1", "l4p3"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
+LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128", "l4c128", "l4c2128", "l4c192", "l4c1192", "l4c3192", "l4c7192", "l4c1256", "l4c2240", "l4c5256", "l4c11192", "l4c15192", "l4c27192", "l4c25192", "l4c59192", "l4c35192", "l4c34128"]
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
@@ -420,13 +420,13 @@ def test_lane_decoder_starved_flush(oracle, gen):
             comps = [oracle.compress(a) for a in blocks]
             for known in (True, False):
                 res, dst = emu.decode([np.concatenate([c, np.zeros(64, np.uint8)]) for c in comps], [a.size for a in blocks], known=known,
-                                      src_lens=None if known else [len(c) for c in comps], lane=27192 if gen == 4 else 128, stage=64, gen=gen)
+                                      src_lens=None if known else [len(c) for c in comps], lane=59192 if gen == 4 else 128, stage=64, gen=gen)
                 for i, (a, c) in enumerate(zip(blocks, comps)):
                     assert res[i] == (len(c) if known else a.size), (known, i, res[i])
                     assert np.array_equal(dst[i, :a.size], a), (known, i)
         # the odd-but-legal and malformed streams and the error-code matrix, in the same starved state
-        test_decode_arbitrary_streams(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c27192"}[gen])
-        test_decode_error_codes_match_oracle(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c27192"}[gen])
+        test_decode_arbitrary_streams(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c59192"}[gen])
+        test_decode_error_codes_match_oracle(oracle, {2: "lane128s64", 3: "l3r128", 4: "l4c59192"}[gen])
 
 
 @pytest.mark.parametrize("lane", [False] + LANE3, ids=["wave-per-block"] + LANE3)
