@@ -9,18 +9,27 @@
 // F(c) >= 4 and F(c) > ml.  And F along a chain follows from the table: with c' the chain predecessor of c and
 // lcp[c] = the common length of c and c',
 //      F(c') = min(F(c), lcp[c])   if F(c) != lcp[c],          F(c') >= F(c)   if they are equal (then compare on from there).
-// The table entry of position p is  chain[p] | lcp[p] << 16  (u32; lcp capped at 255 = "255 or more: compare on", and at
-// matchlimit - p, which no search from a later position can reach), built up front for every position by two kernels:
+// The table entry of position p is  chain[p] | lcp[p] << 16 | y[p] << 24  (u32; lcp capped at 255 = "255 or more: compare on", and at
+// matchlimit - p, which no search from a later position can reach; y[p] = the predecessor's byte BEHIND the shared bytes,
+// in[p - chain[p] + lcp[p]] -- round 5).  The equal case F(c) == lcp[c] used to cost a 16-byte compare of the input (a third of
+// the hops of fuzzer-style data, each a random sector of the block): F(c') > lcp[c] iff in[ip + lcp[c]] == y[c], and that one
+// byte of the search position's side is in the lane's register window nearly always -- so the walk only compares when the
+// byte does match.  Built up front for every position by two kernels:
 // hc_nat_chain_kernel<uint32_t> (natural chains, lz4hip_hc_nat.hpp) and hc_lcp_fill_kernel (the block staged in LDS, one
 // position per thread).  The first candidate's length is lcp[ip] itself (the entry of the search position, read before ip is
 // inserted: its predecessor is the bucket's head), so the repeat detection (lz4hc.c:411-421) needs no input either.
-// The repeat fill (lz4hc.c:437-455) writes  delta | min(255, ip + repl - q) << 16  for q in [ip, end): the run's positions
-// share exactly the rest of the matched region with their predecessor at distance delta.
+// The repeat fill (lz4hc.c:437-455) writes  delta | min(255, ip + repl - q) << 16 | in[ip + repl - delta] << 24  for q in [ip, end):
+// the run's positions share exactly the rest of the matched region with their predecessor at distance delta, and the byte
+// behind it on the predecessor's side is the same for all of them.
 // The wider-match search (lz4hc.c:462-518) walks the same way; its filter byte *(startLimit + longest) vs
 // *(ref - delta + longest) lies inside the known common region for almost every candidate (no load), the backward extension
 // reads the input as before.
 #pragma once
 #include "lz4hip_hc_nat.hpp"
+
+#ifndef LZ4HIP_STAT
+#define LZ4HIP_STAT(slot, cond) ((void)0)   /* the emulator build counts lane-steps per state (tools/emu_hc_stats.py) */
+#endif
 
 namespace lz4hip {
 
@@ -147,7 +156,11 @@ __global__ void __launch_bounds__(kHcLcpFillThreads) hc_lcp_fill_kernel(Batch b,
             int room = matchlimit - p;
             room = room < 0 ? 0 : (room > kHcLcpCap ? kHcLcpCap : room);
             const uint32_t len = r[u] > (uint32_t)room ? (uint32_t)room : r[u];
-            if (p <= lastp) table[p] = (e[u] & 0xFFFFu) | (len << 16);
+            // the predecessor's byte behind the shared bytes (only looked at when len is a real mismatch distance: a length at
+            // one of its caps never takes part in the walk's equal case)
+            const int yp = p - (int)(e[u] & 0xFFFFu) + (int)len;
+            const uint32_t y = lds[yp < 0 ? 0 : (yp < n ? yp : n - 1)];
+            if (p <= lastp) table[p] = (e[u] & 0xFFFFu) | (len << 16) | (y << 24);
         }
 #pragma unroll
         for (int k = 0; k < U; k++) e[k] = e2[k];
@@ -193,6 +206,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
     int s_f = 0;                   // F(s_ref): exact common length of in[s_ip..] and in[s_ref..], capped at matchlimit - s_ip
     int s_first = 0;               // s_ref is the bucket's head (the repeat detection looks at it, lz4hc.c:411)
     int s_link = 0, s_lcp = 0;     // entry of s_ref (kept across the backward extension)
+    uint32_t s_y = 0, s_ry = 0;    // ... its predecessor's byte behind the shared bytes; the same byte for the entries of a repeat fill
     int attempts = 0;
     uint32_t s_probe = 0;
     int s_probe_ok = 0;            // s_probe is in[start_limit + longest] for the current s_len (wider)
@@ -210,6 +224,13 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
         const uint32_t a0 = pick(iw0, iw1, iw2, iw3, iw4), a1 = pick(iw1, iw2, iw3, iw4, iw5), a2 = pick(iw2, iw3, iw4, iw5, iw6),
                        a3 = pick(iw3, iw4, iw5, iw6, iw7), a4 = pick(iw4, iw5, iw6, iw7, 0u);
         return Vec16{ { wv::alignbyte(a1, a0, sh), wv::alignbyte(a2, a1, sh), wv::alignbyte(a3, a2, sh), wv::alignbyte(a4, a3, sh) } };
+    };
+
+    auto win_byte = [&](int o) -> uint32_t {                         // byte o of the window, 0 <= o < 32
+        // (selects that STAY selects, wv::sel: written as nested ?: over eight scalars the compiler builds an indexed array in scratch memory)
+        const wv::mask_t m1 = wv::cond((o & 4) != 0), m2 = wv::cond((o & 8) != 0), m4 = wv::cond((o & 16) != 0);
+        const uint32_t lo = wv::sel(m2, wv::sel(m1, iw3, iw2), wv::sel(m1, iw1, iw0)), hi = wv::sel(m2, wv::sel(m1, iw7, iw6), wv::sel(m1, iw5, iw4));
+        return (wv::sel(m4, hi, lo) >> (8u * ((uint32_t)o & 3u))) & 255u;
     };
 
     auto request = [&](int pos, int start_limit, int longest, int match0, int start0_) {
@@ -242,6 +263,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
 
         // ================= one memory step of the state each lane is in =================
         const bool inH = st == kLsHead, inP = st == kLsHop, inC = st == kLsCmp, inB = st == kLsBack, inL = st == kLsRepl;
+        LZ4HIP_STAT(0, st != kLsExit); LZ4HIP_STAT(1, inH); LZ4HIP_STAT(2, inP); LZ4HIP_STAT(3, inC); LZ4HIP_STAT(4, inB); LZ4HIP_STAT(5, inL); LZ4HIP_STAT(6, st == kLsCtrl);
         const int f_a = s_ip + c_n, f_b = s_ref + c_n;
         const bool cmp16 = inC & (f_a + 16 <= matchlimit);
         const bool back4 = inB & (c_s - s_limit >= 4) & (c_r >= 4);
@@ -268,12 +290,15 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
         if (cmp16) v_y = load_v16(in + f_b);
         if (cmp16 & !w_hit) v_x = load_v16(in + f_a);
         if (w_fill) v_x2 = load_v16(in + f_a + 16);
+        // (8) repeat fill, first step: the byte behind the run on its predecessor's side (what its entries carry as y)
+        uint32_t v_rb = 0;
+        if (inL & (s_repl > 0)) v_rb = in[s_ip + s_repl - s_delta];
 
         // ---- process ----
         bool adv = false;                                            // the walk moves on to the next candidate (below, once)
         if (inH) {                                                   // HASH_POINTER(ip) after LZ4HC_Insert(ip) == ip - natural chain[ip]
             s_ref = s_ip - (int)(v_e & 0xFFFFu);
-            s_f = (int)(v_e >> 16);
+            s_f = (int)((v_e >> 16) & 255u);
             s_first = 1;
             if (s_f >= kHcLcpCap) { c_n = kHcLcpCap; st = kLsCmp; }
             else st = kLsHop;                                        // (blocks <= 64 KiB: the head is always within MAX_DISTANCE)
@@ -308,7 +333,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             }
         }
         if (hop_now) {
-            s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)(v_e >> 16);
+            s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)((v_e >> 16) & 255u); s_y = v_e >> 24;
             if (phase == 0) {
                 if (s_first && s_ref >= s_ip - 4) {                  // lz4hc.c:411-421: not one of the attempts
                     if (s_f >= kMinMatch) { s_delta = (s_ip - s_ref) & 0xFFFF; s_repl = s_len = s_f; s_match = s_ref; }
@@ -347,9 +372,9 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
                 adv = true;
             }
         } else if (inL) {                                            // lz4hc.c:437-455: DELTANEXT(q) = delta for q in [ip, end)
-            if (s_repl > 0) { c_s = s_ip; c_r = s_ip + s_repl - 3; c_fwd_end = s_ip + s_repl; s_repl = -1; }
+            if (s_repl > 0) { c_s = s_ip; c_r = s_ip + s_repl - 3; c_fwd_end = s_ip + s_repl; s_repl = -1; s_ry = v_rb; }
             int q = c_s;
-            const uint32_t d = (uint32_t)s_delta;
+            const uint32_t d = (uint32_t)s_delta | (s_ry << 24);
             auto entry = [&](int at) -> uint32_t { const int l = c_fwd_end - at; return d | ((uint32_t)(l > kHcLcpCap ? kHcLcpCap : l) << 16); };
             if ((q & 3) == 0 && q + 4 <= c_r) {
                 store_v16((uint8_t*)(table + q), Vec16{ { entry(q), entry(q + 1), entry(q + 2), entry(q + 3) } });
@@ -368,9 +393,23 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             else {
                 const int l = s_lcp;
                 s_ref = c2; s_first = 0;
+                LZ4HIP_STAT(7, true);
                 if (s_f < l) st = kLsHop;                                        // F(c') = F(c)
                 else if (s_f > l && l < kHcLcpCap) { s_f = l; st = kLsHop; }     // F(c') = lcp[c]
-                else { c_n = l; st = kLsCmp; }                                   // equal, or both >= 255: at least l, compare on
+                else {
+                    // equal, or both >= 255: F(c') is at least l.  Equal and below the cap: it is MORE than l only if the search
+                    // position's byte l equals the predecessor's (y of the entry just left) -- a look at the register window
+                    // instead of a 16-byte compare; at matchlimit - s_ip nothing can be added either.
+                    const int pos = s_ip + l;
+                    bool exact = false;
+                    if (l < kHcLcpCap) {
+                        if (pos >= matchlimit) exact = true;
+                        else if ((pos >= w_pos) & (pos < w_pos + 32)) exact = win_byte(pos - w_pos) != s_y;
+                    }
+                    LZ4HIP_STAT(8, true); LZ4HIP_STAT(9, l < kHcLcpCap); LZ4HIP_STAT(10, (l < kHcLcpCap) & (pos >= w_pos) & (pos < w_pos + 32)); LZ4HIP_STAT(11, exact);
+                    if (exact) st = kLsHop;                                      // F(c') = l = F(c)
+                    else { c_n = l; st = kLsCmp; }                               // compare on
+                }
             }
         }
         // A best-match search that is complete needs no sequence encode to know the next search (lz4hc.c:586-597: no match ->
