@@ -43,10 +43,10 @@ def csrc_sha() -> str:
 
 def committed_traffic(kind: str, dist: int, blocks: int):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
-    from profiles/r04 (or an earlier round)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel
+    from profiles/r05 (or an earlier round)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel
     sources and this workload; otherwise None (a stale number would be a lie)."""
     sha = csrc_sha()
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if not os.path.exists(f):
             continue
@@ -612,7 +612,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("lz4hip::decode_kernel<true> (one wavefront per block)" if wave_mapped
-                       else "lz4hip::decode_lane4_kernel<true,192,32,128,2,2,2,0> (one lane per block: input window in registers, 192-byte LDS output ring, 128-byte flush units, hand-counted vmcnt)"),
+                       else "lz4hip::decode_lane4_kernel<true,192,32,128,2,2,2,16> (one lane per block: input window in registers fed from whole 64-byte sectors, 192-byte LDS output ring with rows stored twice instead of wrapped, 128-byte flush units, hand-counted vmcnt)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes_local, "mean_kernel_ms": round(mean_kernel_ms, 4),

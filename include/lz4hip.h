@@ -131,8 +131,8 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 2 and 3 exist only in libraries built with -DLZ4HIP_TUNING_BUILD) and, for generation 4, its
  *                                 configuration: bytes of output ring per lane + 1000 x variant (bit 0: 128-byte flush units,
  *                                 bit 1: 32-byte input pieces, bit 2: one flush store instruction instead of two, bit 3: the flush runs in every second
- *                                 iteration only, bit 4: input pieces are requested in the other iterations only; 0 = default 27192;
- *                                 other configurations exist only in tuning builds)
+ *                                 iteration only, bit 4: input pieces are requested in the other iterations only, bit 5: the pieces come out of whole
+ *                                 64-byte sectors fetched once; 0 = default 59192; other configurations exist only in tuning builds)
  *   "hc_gen"                     [LZ4HIP_HC_GEN]  LZ4HC lane mapping: 0 default (4 for blocks <= 64 KiB, else 2); 4 the state machine over
  *                                 precomputed chains that carry shared lengths (lz4hip_hc_lcp.hpp), 2 the state machine with the
  *                                 insert loop (lz4hip_hc_conv.hpp: blocks > 64 KiB; smaller ones only in tuning builds); 1 and 3 (one

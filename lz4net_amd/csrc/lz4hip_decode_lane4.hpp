@@ -17,6 +17,15 @@
 //     (log2(P/4) levels; measured: 4.5 SIMD-cycles per select, tools/microbench_select_tree.hip) and one byte rotation;
 //     the offset field of a sequence is picked out of those 16 bytes the same way.
 //   * LDS per wavefront = 64 x R + 512 bytes: R = 192 at the twelve wavefronts per CU generation 3 had with R = 128.
+// Round 5 (profiles/r05/decoder_sector_input_and_dual_stores_ab.txt; D2 at 2^20 blocks 1020 -> 1040-1064 GB/s, D3 825 -> 833-840):
+//   * SECTOR INPUT (POL bit 4, the default): L is a whole aligned 64-byte sector -- four loads, ONE request to the memory side -- and
+//     feeds W a 32-byte half at a time.  Window and select tree stay those of 32-byte pieces (+8 selects for the choice of the half), but a
+//     sector of the source is fetched once instead of as two halves ~10 us apart, the second after its line had left the L2: 0.5 G of a
+//     launch's 3.7 G requests gone.
+//   * RING ROWS STORED TWICE instead of wrapped (LZ4HIP_DEC4_DUAL_STORE): gfx950 drops a DS store outside the workgroup's allocation
+//     (tools/lds_out_of_range.hip), so the rows of an append go to `row` and to `row - ring size` (ds_write2st64_b32: two rows per
+//     instruction) and the three instructions per row address that a ring of 48 rows cost are gone: -19 of ~305 vector-ALU instructions per
+//     iteration.  Worth nothing while the request ceiling held (round 4), +2.5 % behind the sector input.
 // Everything else is generation 3's design: dword-interleaved output ring, appends by DS_MSKOR_B32 + v_perm_b32, cooperative
 // flush (four lanes per 64-byte line, or eight per 128-byte unit), far matches fetched from the lane's own output one and a
 // half iterations ahead, parse-ahead of one sequence, a byte-wise parser behind one wave-level branch, hand-counted vmcnt.

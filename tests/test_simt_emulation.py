@@ -25,8 +25,8 @@ def _mapping(m):
     return {}
 
 
-LANE3 = ["l3r128", "l3r240", "l4c11192", "l4c27192", "l4c59192", "l4p1", "l4p3"]    # third generation: a power-of-two ring and another one; fourth generation (the product's): the default and 32-byte pieces
-LANE3_ALL = ["l3r128", "l3r176", "l3r240", "l3r256s128", "l4c128", "l4c2128", "l4c192", "l4c1192", "l4c3192", "l4c7192", "l4c1256", "l4c2240", "l4c5256", "l4c11192", "l4c15192", "l4c27192", "l4c25192", "l4c59192", "l4c35192", "l4c34128"]
+LANE3 = ["l3r128", "l3r240", "l4c27192", "l4c59192", "l4p1", "l4p3"]    # third generation (tools/ab, A/B only): a power-of-two ring and another one; the product's lane decoder: the round-4 default, the default (sector input), its persistent form with one / three wavefronts
+LANE3_ALL = ["l3r128", "l3r240", "l4c128", "l4c192", "l4c1192", "l4c7192", "l4c2240", "l4c5256", "l4c27192", "l4c35192", "l4c59192"]
 
 
 def _blocks(oracle, sizes=SIZES, seeds=(5,)):
