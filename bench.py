@@ -138,9 +138,9 @@ class Workload:
         self.used = torch.empty(n, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         # warm-up launches on slivers (module load; the lane encoder's per-device table workspace is allocated by
-        # the first batch of >= 16384 blocks), then the timed single-pass encode
+        # the first batch of >= 32768 blocks), then the timed single-pass encode
         batch.encode(self.raw[:64], batch.BLOCK, self.comp[:64], batch.BOUND, result=self.clen[:64])
-        k = min(n, 16384)
+        k = min(n, 32768)
         batch.encode(self.raw[:k], batch.BLOCK, self.comp[:k], batch.BOUND, result=self.clen[:k])
         torch.cuda.synchronize()
         self.encode_ms = min(event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
@@ -486,6 +486,31 @@ def main():
                 }
                 del raw, comp, back
         if not args.hc_only:
+            # ---- what smaller batches get (device-resident, default dispatch): the lane mappings need the chip full, below
+            #      16 384 (decode) / 32 768 (fast encode) blocks the wavefront mappings run alone (their time is one wavefront's instruction count) ----
+            torch.cuda.empty_cache()
+            sweep = {}
+            m_max = min(1 << 18, n)
+            raw_s = batch.synth(args.dist, seed, 0, m_max)
+            comp_s = torch.empty((m_max, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+            clen_s = batch.encode(raw_s, batch.BLOCK, comp_s, batch.BOUND)
+            back_s = torch.empty_like(raw_s)
+            last_m = 0
+            for m in (1024, 4096, 16384, 65536, 262144):
+                if m > m_max:
+                    continue
+                last_m = m
+                batch.decode(comp_s[:m], clen_s[:m], back_s[:m], batch.BLOCK)
+                torch.cuda.synchronize()
+                t_dec = min(event_ms(lambda: batch.decode(comp_s[:m], clen_s[:m], back_s[:m], batch.BLOCK), torch) for _ in range(3))
+                entry = {"decode_GBps": round(m * batch.BLOCK / (t_dec / 1e3) / 1e9, 2)}
+                if m <= 65536:
+                    t_enc = min(event_ms(lambda: batch.encode(raw_s[:m], batch.BLOCK, comp_s[:m], batch.BOUND), torch) for _ in range(2))
+                    entry["encode_fast_GBps"] = round(m * batch.BLOCK / (t_enc / 1e3) / 1e9, 2)
+                sweep[str(m)] = entry
+            sweep["ok"] = last_m > 0 and batch.count_mismatches(raw_s[:last_m], back_s[:last_m], batch.BLOCK) == 0
+            extras["batch_size_sweep_" + DIST_NAMES[args.dist].split("(")[0]] = sweep
+            del raw_s, comp_s, back_s
             # ---- the HBM roof measured on this box (quote the 8 TB/s spec AND what a copy reaches) ----
             torch.cuda.empty_cache()
             words = (4 << 30) // 8

@@ -390,6 +390,27 @@ def test_decode_arbitrary_streams(gpu, oracle, decoder):
         assert (dst[i, max(cap, 0):] == 0xA5).all(), ("unknown canary", i)
 
 
+def test_lds_out_of_range_stores_are_dropped(gpu, tmp_path):
+    """The hardware rule the lane decoder's appends rest on since round 5 (lz4hip_decode_lane4.hpp, LZ4HIP_DEC4_DUAL_STORE): a DS store
+    whose address lies outside the workgroup's LDS allocation is DROPPED -- no fault, no word of any co-resident workgroup's allocation
+    changes.  tools/lds_out_of_range.hip checks exactly that (twelve workgroups of the decoder's 12 800 bytes resident per CU, 2 000 rounds
+    of out-of-range stores per lane, past the end and below address 0); a device on which it fails would corrupt decoded bytes, and
+    this test says why before the decoder tests do."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box: the decoder tests themselves remain the check")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lds_out_of_range.hip")
+    exe = str(tmp_path / "lds_out_of_range")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", src, "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "pattern words changed in any workgroup's allocation: 0 " in r.stdout
+
+
 def test_decoder_fuzz_slice(gpu, oracle):
     """A 30-second slice of tools/fuzz_gpu_decoders.py in every -m gpu run (tests/decoder_fuzz.py): arbitrary streams x known / unknown
     output size x the three decoder forms -- wavefront mapping with bursts, lane mapping, the persistent lane grid with ONE wavefront
