@@ -139,3 +139,7 @@ def test_tuning_knobs_without_gpu():
     with _lib.tuning(decoder="lane", hc_groups=4):
         assert _lib.tuning_get("decoder") == 2 and _lib.tuning_get("hc_groups") == 4
     assert _lib.tuning_get("decoder") == 0 and _lib.tuning_get("hc_groups") == 0
+    # read-only: what the lane encoder's table slab measured (no slab without a device: all zero, and not settable)
+    for name in ("encoder_slab_rate", "encoder_slab_tried", "encoder_slab_chunks"):
+        assert _lib.tuning_get(name) == 0
+        assert L.lz4hip_tuning_set(name.encode(), 1) == _lib.E_ARGUMENT
