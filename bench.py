@@ -31,14 +31,10 @@ DIST_NAMES = {0: "D0-zeros", 1: "D1-incompressible", 2: "D2-fuzzer(original/fuzz
 
 
 def csrc_sha() -> str:
-    """Hash of the kernel sources: committed PMC traffic figures are only quoted for the code they were measured on."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "lz4net_amd", "csrc", "*"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the kernel sources: committed PMC traffic figures are only quoted for the code they were measured on, and the
+    library says which sources IT was compiled from (lz4hip_build_id) -- the two must agree before anything is measured."""
+    from lz4net_amd import build as hip_build
+    return hip_build.csrc_sha()
 
 
 def committed_traffic(kind: str, dist: int, blocks: int):
@@ -46,7 +42,7 @@ def committed_traffic(kind: str, dist: int, blocks: int):
     from profiles/r05 (or an earlier round)/pmc_traffic.json -- only if that file was produced from EXACTLY these kernel
     sources and this workload; otherwise None (a stale number would be a lie)."""
     sha = csrc_sha()
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if not os.path.exists(f):
             continue
@@ -203,21 +199,35 @@ def full_corpus_encoder_check(torch, batch, comp, clen, hc, dist, seed, first, s
             "what": "per block: compressed length and 64-bit checksum of the compressed bytes, GPU rows vs the CPU codec on the regenerated block"}
 
 
-def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
-    """The CPU codec on this box's host cores, bounded sample of the same workload (same generator,
-    same seed, first `sample_blocks` blocks).  Also the bench's parity spot check: the GPU's compressed
-    bytes for those blocks must equal the CPU reference's."""
+def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks, raw=None):
+    """The CPU codec on this box's host cores, bounded sample of the same workload (the first `sample_blocks` blocks of the GPU
+    batch: copied from it, or regenerated by the CPU twin of the generator).  All three legs the same way -- best of N passes over
+    the whole sample, N bounded by time (the method of the reference's own timers: src/LZ4.Tests.Helpers/TimedMethod.cs:66-69,
+    original/bench.c:402-443 keep the best of repeated runs).  Also the bench's parity spot check: the GPU's compressed bytes for
+    the first blocks must equal the CPU reference's."""
     import numpy as np
     from oracle.oracle import Oracle, Reference
     o = Oracle()
     codec, kind = (Reference(), "reference") if Reference.available() else (o, "port")
     cores = os.cpu_count() or 1
-    raw = o.gen(dist, seed, 0, sample_blocks)
+    if raw is None:
+        raw = o.gen(dist, seed, 0, sample_blocks)
+    else:
+        assert raw.shape[0] == sample_blocks and np.array_equal(raw[:8], o.gen(dist, seed, 0, 8)), "sample is not the head of the workload"
     bound = 65536 + 65536 // 255 + 16
     comp = np.zeros((sample_blocks, bound), np.uint8)
     lens = np.full(sample_blocks, 65536, np.int32)
     caps = np.full(sample_blocks, bound, np.int32)
-    t_enc, clen = o.batch(codec, "enc", raw, lens, comp, caps, threads=cores)
+
+    def best_of(fn, seconds, min_passes=3, max_passes=50):
+        best, passes, t0, last = None, 0, time.time(), None
+        while passes < min_passes or (time.time() - t0 < seconds and passes < max_passes):
+            t, last = fn()
+            best = t if best is None else min(best, t)
+            passes += 1
+        return best, passes, last
+
+    t_enc, enc_passes, clen = best_of(lambda: o.batch(codec, "enc", raw, lens, comp, caps, threads=cores), 6.0)
     parity = None
     if gpu_comp_sample is not None:
         g_comp, g_len = gpu_comp_sample
@@ -225,19 +235,13 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
         parity = bool((g_len[:k] == clen[:k]).all()) and all(
             np.array_equal(g_comp[i, :clen[i]], comp[i, :clen[i]]) for i in range(k))
     back = np.zeros_like(raw)
-    best = None
-    t0 = time.time()
-    passes = 0
-    while passes < 3 or (time.time() - t0 < 8.0 and passes < 50):
-        t, res = o.batch(codec, "dec", comp, clen, back, lens, threads=cores)
-        assert (res == clen).all()
-        best = t if best is None else min(best, t)
-        passes += 1
+    best, passes, res = best_of(lambda: o.batch(codec, "dec", comp, clen, back, lens, threads=cores), 6.0)
+    assert (res == clen).all()
     assert np.array_equal(back, raw)
-    # LZ4HC on a quarter of the sample (it is ~5x slower per core than the fast encoder)
-    hc_blocks = max(cores, sample_blocks // 4)
-    hc_blocks = min(hc_blocks, sample_blocks)
-    t_hc, hlen = o.batch(codec, "hc", raw[:hc_blocks], lens[:hc_blocks], comp[:hc_blocks], caps[:hc_blocks], threads=cores)
+    # LZ4HC on a quarter of the sample (it is ~4x slower per core than the fast encoder), same best-of-N
+    hc_blocks = min(max(cores, sample_blocks // 4), sample_blocks)
+    hcomp = np.zeros((hc_blocks, bound), np.uint8)
+    t_hc, hc_passes, hlen = best_of(lambda: o.batch(codec, "hc", raw[:hc_blocks], lens[:hc_blocks], hcomp, caps[:hc_blocks], threads=cores), 6.0)
     assert (hlen > 0).all()
     return {
         "value": round(sample_blocks * 65536 / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
@@ -245,11 +249,12 @@ def cpu_baseline(dist, seed, gpu_comp_sample, sample_blocks):
                   "built with the flags of its 64-bit native back-end" if kind == "reference" else
                   "C oracle stand-in for LZ4pn: from-scratch C restatement (oracle/lz4_oracle.c)"),
         "cpu_model": cpu_model(),
-        "sample": f"{sample_blocks} x 64 KiB {DIST_NAMES[dist]} blocks (first blocks of the GPU batch), decode, "
-                  f"best of {passes} passes, {cores} threads; encode on the same sample "
-                  f"{round(sample_blocks * 65536 / t_enc / 1e9, 3)} GB/s",
-        "encode_value": round(sample_blocks * 65536 / t_enc / 1e9, 3),
-        "encode_hc_value": round(hc_blocks * 65536 / t_hc / 1e9, 3), "encode_hc_sample_blocks": hc_blocks,
+        "sample": f"{sample_blocks} x 64 KiB {DIST_NAMES[dist]} blocks (first blocks of the GPU batch, {sample_blocks * 65536 >> 20} MiB raw), {cores} threads, "
+                  f"every leg best of N whole passes: decode best of {passes}, fast encode best of {enc_passes} "
+                  f"({round(sample_blocks * 65536 / t_enc / 1e9, 3)} GB/s), LZ4HC on the first {hc_blocks} blocks best of {hc_passes}",
+        "encode_value": round(sample_blocks * 65536 / t_enc / 1e9, 3), "encode_passes": enc_passes,
+        "encode_hc_value": round(hc_blocks * 65536 / t_hc / 1e9, 3), "encode_hc_sample_blocks": hc_blocks, "encode_hc_passes": hc_passes,
+        "decode_passes": passes,
         "gpu_bytes_equal_cpu_reference": parity,
     }
 
@@ -295,6 +300,10 @@ def main():
         dist.barrier()
     from lz4net_amd import batch, _lib
     _lib.lib()
+    # the binary that is about to be measured must be the one these sources produce (prebuilt .so files travel between boxes)
+    lib_id = _lib.lib().lz4hip_build_id().decode()
+    if lib_id.split("+")[0] != csrc_sha():
+        raise SystemExit(f"bench.py: lz4net_amd/liblz4hip.so was built from csrc {lib_id}, the tree holds {csrc_sha()}: refusing to measure a stale library")
 
     def barrier():
         torch.cuda.synchronize()
@@ -308,6 +317,13 @@ def main():
     per_block += args.dst_pad
     while n * per_block * 1.03 > free and n > 1024:
         n //= 2
+    if world > 1:
+        # every rank must run the SAME shard size (weak scaling: blocks_per_gpu is one number): the smallest any rank can hold
+        nt = torch.tensor([n], dtype=torch.int64)
+        dist.all_reduce(nt, op=dist.ReduceOp.MIN)
+        if int(nt.item()) != n:
+            print(f"[bench] rank {rank}: {n} blocks would fit here, another rank holds fewer: every rank runs {int(nt.item())}", file=sys.stderr)
+        n = int(nt.item())
     # round-robin shard of a global batch of n*world blocks: local block j is global block j*world + rank
     seed = args.seed
     _lib.tuning_set("decoder", args.decoder)
@@ -363,10 +379,15 @@ def main():
     # ---- extras: the other distributions (decode) and the encoders, rank 0 at N == 1 only -----------
     extras = {}
     gpu_sample = None
-    sample_blocks = min(2048, n)
+    # cpu_baseline sample: 16 384 blocks (1 GiB raw -- not LLC-resident on a 256 MiB-L3 host) where the host has the cores to get through
+    # it in seconds, 2 048 otherwise; the raw blocks are the GPU batch's own first blocks (copied out here, wl is freed below)
+    sample_blocks = min(16384 if (os.cpu_count() or 1) >= 32 else 2048, n)
+    raw_sample = None
     if rank == 0:
         k = min(64, n)
         gpu_sample = (wl.comp[:k].cpu().numpy(), wl.clen[:k].cpu().numpy())
+        if world == 1 and not args.no_cpu:
+            raw_sample = wl.raw[:sample_blocks].cpu().numpy()
     head = {
         "decode_GBps": round(wl.raw_bytes / (sum(kernel_ms) / len(kernel_ms) / 1e3) / 1e9, 2),
         "encode_fast_GBps": round(wl.raw_bytes / (wl.encode_ms / 1e3) / 1e9, 2),
@@ -530,7 +551,10 @@ def main():
             import ctypes as C
             import numpy as np
 
-            def host_decode_rate(m):
+            def host_decode_rate(m, multi=False):
+                L = _lib.lib()
+                dec_call = (lambda b: L.lz4hip_decode_batch_host_multi(C.byref(b), 1, 0)) if multi else (lambda b: L.lz4hip_decode_batch_host(C.byref(b), 1))
+                enc_call = (lambda b: L.lz4hip_encode_batch_host_multi(C.byref(b), 0, 0)) if multi else (lambda b: L.lz4hip_encode_batch_host(C.byref(b), 0))
                 raw_d = batch.synth(args.dist, seed, 0, m)
                 comp_d = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
                 clen_h = batch.encode(raw_d, batch.BLOCK, comp_d, batch.BOUND).cpu().numpy().astype(np.int32)
@@ -542,11 +566,11 @@ def main():
                 hb = _lib.Batch(src=comp_h.ctypes.data, src_off=None, src_stride=comp_h.strides[0], src_len=clen_h.ctypes.data,
                                 dst=back_h.ctypes.data, dst_off=None, dst_stride=back_h.strides[0], dst_cap=caps_h.ctypes.data,
                                 dst_cap_all=0, src_len_all=0, result=res_h.ctypes.data, n_blocks=m)
-                _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
+                _lib.check(dec_call(hb))
                 t_host = None
                 for _ in range(3):
                     t1 = time.perf_counter()
-                    _lib.check(_lib.lib().lz4hip_decode_batch_host(C.byref(hb), 1))
+                    _lib.check(dec_call(hb))
                     dt = time.perf_counter() - t1
                     t_host = dt if t_host is None else min(t_host, dt)
                 ok_h = bool((res_h == clen_h).all()) and bool(np.array_equal(back_h, raw_h))
@@ -559,11 +583,11 @@ def main():
                 eb = _lib.Batch(src=raw_h.ctypes.data, src_off=None, src_stride=raw_h.strides[0], src_len=elen_h.ctypes.data,
                                 dst=enc_h.ctypes.data, dst_off=None, dst_stride=enc_h.strides[0], dst_cap=ecap_h.ctypes.data,
                                 dst_cap_all=0, src_len_all=batch.BLOCK, result=eres_h.ctypes.data, n_blocks=m)
-                _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(eb), 0))
+                _lib.check(enc_call(eb))
                 t_enc = None
                 for _ in range(3):
                     t1 = time.perf_counter()
-                    _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(eb), 0))
+                    _lib.check(enc_call(eb))
                     dt = time.perf_counter() - t1
                     t_enc = dt if t_enc is None else min(t_enc, dt)
                 ok_e = bool((eres_h == clen_h).all()) and all(np.array_equal(enc_h[i, :clen_h[i]], comp_h[i, :clen_h[i]]) for i in range(0, m, max(m // 256, 1)))
@@ -579,6 +603,19 @@ def main():
                 "note": "lz4hip_decode_batch_host on pageable host arrays: gather + H2D + kernels + D2H + scatter, best of 3 "
                         "(reported beside, never as, `value`); a batch is cut into 1-6 slices (one per ~2048 blocks) whose copies and kernels overlap",
             }
+            # ---- the same call through the C ABI's OWN sharding (lz4hip_*_batch_host_multi, device_mask 0 = every visible device: block i -> device
+            #      i mod N, one persistent worker per device): the single-process form of BASELINE configs[4].  On a one-GPU box the knob
+            #      logical_devices makes two workers share the device -- a recorded rate of the code path, not a scaling point ----
+            ndev = _lib.lib().lz4hip_device_count()
+            logical = 0 if ndev > 1 else 2
+            with _lib.tuning(logical_devices=logical):
+                mrate, mok, merate, meok = host_decode_rate(m_big, multi=True)
+            extras["host_pointer_batch_multi_device"] = {
+                "decode_GBps": mrate, "encode_fast_GBps": merate, "blocks": m_big, "visible_devices": ndev,
+                "device_workers": ndev if ndev > 1 else logical, "ok": mok and meok,
+                "note": "lz4hip_decode/encode_batch_host_multi, device_mask 0, round-robin shards, results in global order; with one visible device two "
+                        "workers share it (knob logical_devices): the threaded path's rate, not a multi-GPU measurement",
+            }
 
     if rank != 0:
         if world > 1:
@@ -589,7 +626,7 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu:
         try:
-            cpu = cpu_baseline(args.dist, seed, gpu_sample, sample_blocks)
+            cpu = cpu_baseline(args.dist, seed, gpu_sample, sample_blocks, raw_sample)
         except Exception as e:   # the bench line must still be printed
             cpu = {"error": repr(e)}
 
@@ -648,7 +685,7 @@ def main():
         "roofline_hc": side_roofline(hc_roof, "encode_hc", "lz4hip::hc_nat_chain_kernel + hc_lcp_fill_kernel + encode_hc_lcp_kernel (LZ4_compressHCCtx: chains and shared lengths of every position built up front, then one lane per block, convergent state machine without the insert loop)", hc_check),
         "cpu_baseline": cpu,
         "verified": all_ok,
-        "csrc_sha": csrc_sha(),
+        "csrc_sha": csrc_sha(), "library_build_id": lib_id,
         "extras": extras,
     }
     print(json.dumps(line))

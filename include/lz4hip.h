@@ -42,6 +42,10 @@ extern "C" {
 const char* lz4hip_codec_name(void);
 int         lz4hip_device_count(void);
 const char* lz4hip_last_error(void);
+/* The kernel sources this binary was compiled from: the first 16 hex digits of the SHA-256 over lz4net_amd/csrc/ (file names + contents, sorted;
+ * lz4net_amd/build.py csrc_sha()), "+tuning" appended for -DLZ4HIP_TUNING_BUILD libraries, "unknown" for a build that bypassed build.py.
+ * bench.py prints it next to the hash of the tree it runs from and refuses to measure when the two differ. */
+const char* lz4hip_build_id(void);
 
 /* LZ4_compressBound (original/lz4.h:85-86) == LZ4Codec.MaximumOutputLength (src/LZ4ps/LZ4Codec.cs:142-145). */
 int lz4hip_compressBound(int isize);
@@ -89,7 +93,8 @@ typedef struct lz4hip_batch {
  * slabs >= 2 GiB a few timed probe launches (hipEventSynchronize) on a stream of the library's own, and, when a smaller slab is
  * replaced, one hipDeviceSynchronize before that one is freed (it stays in place if the larger one cannot be had): 0.1 - 3.5 s
  * during which the calling thread blocks and holds the device's encoder workspace.  LZ4HC batches likewise
- * allocate their tables on first use (hipMalloc only).  Every later call is launch-only. */
+ * allocate their tables on first use; GROWING them for a later, larger batch waits for the device (hipDeviceSynchronize) before the old tables
+ * are freed.  The first lane-mapped decode on a device runs a ~1 ms probe launch and waits for it (knob decoder_wrapped_stores).  Every later call is launch-only. */
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream);
 int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream);
 
@@ -152,6 +157,11 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 1 = the first candidate, unmeasured).  Read-only through lz4hip_tuning_get: "encoder_slab_rate" (what the
  *                                 current device's slab measured, 1000 x G probe steps per second; 0 = none / unmeasured), "encoder_slab_tried" (candidates built),
  *                                 "encoder_slab_chunks" (separate allocations the slab in use consists of)
+ *   "decoder_wrapped_stores"     [LZ4HIP_DECODER_WRAPPED_STORES]  lane decoder: its default instantiation stores every ring row at `row` and at `row - ring size`
+ *                                 and relies on gfx950 dropping the LDS store that falls outside the workgroup's allocation; the library CHECKS that rule once per
+ *                                 device before the first lane-mapped decode (a ~1 ms probe launch) and uses the instantiation that wraps its rows instead (same bytes,
+ *                                 a few per cent slower) where the probe does not confirm it.  1 = always the wrapped-row instantiation (debuggers, trap-on-violation
+ *                                 modes).  Read-only through lz4hip_tuning_get: "decoder_dual_store" = 1 if lane-mapped decodes on the current device store twice, else 0
  *   "logical_devices"            [LZ4HIP_LOGICAL_DEVICES]  the *_multi entry points run this many device workers over the
  *                                 selected devices, wrapping around (0 = one per device): exercises the threaded path on one GPU
  * lz4hip_tuning_set returns the previous value (>= 0) or LZ4HIP_E_ARGUMENT; lz4hip_tuning_get the current value. */

@@ -31,6 +31,7 @@ SYMBOLS = [
     ("lz4hip_codec_name", C.c_char_p, []),
     ("lz4hip_device_count", C.c_int, []),
     ("lz4hip_last_error", C.c_char_p, []),
+    ("lz4hip_build_id", C.c_char_p, []),
     ("lz4hip_compressBound", C.c_int, [C.c_int]),
     ("lz4hip_dispatch_counts", C.c_int, [C.c_void_p, C.c_int]),
     ("lz4hip_release_workspaces", C.c_int, []),

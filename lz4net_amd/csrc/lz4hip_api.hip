@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobDecoderWrappedStores, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -66,6 +66,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder_persist", "LZ4HIP_DECODER_PERSIST", false },         // lane decoder, default configuration: 0 the device picks one block per lane or the persistent grid, 1 always persistent, 2 never
     { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
+    { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
 std::atomic<int> g_knob[kKnobCount];
 std::once_flag g_knob_once;
@@ -239,12 +240,14 @@ struct FastSlab {
     void* ctl = nullptr;             // device: the work counter (256 bytes), then the chunk pointers
     double probe = 0;                // G steps per second the placement measured (0: not measured)
     int tries = 0;
+    int64_t failed_groups = 0;       // the smallest slab that could NOT be allocated, and the free device memory at that moment: a request of that
+    size_t failed_free = 0;          // size or more is not tried again until more memory is free (or the workspaces were released)
     void release()
     {
         for (void* c : chunks) (void)hipFree(c);
         chunks.clear();
         if (ctl) { (void)hipFree(ctl); ctl = nullptr; }
-        groups = 0; tables_per_chunk = 0; probe = 0; tries = 0;
+        groups = 0; tables_per_chunk = 0; probe = 0; tries = 0; failed_groups = 0; failed_free = 0;
     }
 };
 FastSlab g_fast_slab[64];
@@ -273,6 +276,17 @@ int fast_slab_reserve(Lease& l, int dev, int64_t groups)
     FastSlab& fs = g_fast_slab[dev];
     if (fs.groups >= groups && fs.ctl) return 0;
     // (a smaller slab that is already there stays until the larger one is built: a failure leaves the old one in place)
+    if (fs.failed_groups > 0 && groups >= fs.failed_groups) {            // this size failed before: not again (multi-GiB hipMallocs) unless memory has been freed since
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (free_b <= fs.failed_free + ((size_t)256 << 20)) return fail(LZ4HIP_E_MEMORY, "workspace allocation failed (not retried: no more device memory free than when it last failed)");
+    }
+    auto remember_failure = [&] {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (fs.failed_groups == 0 || groups < fs.failed_groups) fs.failed_groups = groups;
+        fs.failed_free = free_b;
+    };
     const size_t tables = (size_t)groups * 64;
     const bool large = tables * (size_t)kLaneTableBytes >= ((size_t)2 << 30);   // below 2 GiB: one chunk, nothing to measure
     const int want_tries = !large ? 1 : (knob(kKnobEncoderSlabTries) > 0 ? knob(kKnobEncoderSlabTries) : 4);
@@ -328,7 +342,7 @@ int fast_slab_reserve(Lease& l, int dev, int64_t groups)
     }
     for (auto& h : held) for (void* c : h) (void)hipFree(c);
     if (ps) { (void)hipStreamDestroy(ps); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    if (best.empty()) { (void)hipFree(ctl); return fail(LZ4HIP_E_MEMORY, "workspace allocation failed"); }
+    if (best.empty()) { (void)hipFree(ctl); remember_failure(); return fail(LZ4HIP_E_MEMORY, "workspace allocation failed"); }
     if (hipMemcpy((uint8_t*)ctl + 256, best.data(), 8 * best.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         for (void* c : best) (void)hipFree(c);
@@ -341,6 +355,7 @@ int fast_slab_reserve(Lease& l, int dev, int64_t groups)
         l.w->busy = false;
     }
     fs.chunks.swap(best); fs.tables_per_chunk = best_tpc; fs.groups = groups; fs.ctl = ctl; fs.probe = best_rate > 0 ? best_rate : 0; fs.tries = tried;
+    fs.failed_groups = 0; fs.failed_free = 0;
     return 0;
 }
 
@@ -617,6 +632,43 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
     return 0;
 }
 
+// The lane decoder's dual ring stores (lz4hip_decode_lane4.hpp, L4_APPEND) rest on one hardware rule: a DS store outside the workgroup's LDS
+// allocation is dropped.  That rule is CHECKED here, once per device, before the first lane-mapped decode (lds_drop_probe_kernel: every CU
+// full of workgroups of the decoder's LDS size issuing the decoder's kinds of out-of-range stores; ~1 ms); a device that does not confirm it --
+// or a caller that sets the knob decoder_wrapped_stores -- gets the instantiation whose ring rows are wrapped (POL bit 5), same bytes, ~2 % slower.
+std::atomic<int> g_lds_drop_state[64];       // 0 not probed yet, 1 confirmed, 2 not confirmed (or the probe could not run)
+std::mutex g_lds_drop_mu;
+bool lds_drop_confirmed(int dev)
+{
+    if (dev < 0 || dev >= 64) return false;
+    int st = g_lds_drop_state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        std::lock_guard<std::mutex> lk(g_lds_drop_mu);
+        st = g_lds_drop_state[dev].load(std::memory_order_acquire);
+        if (st == 0) {
+            st = 2;
+            int cus = 0;
+            unsigned* d = nullptr;
+            unsigned h = ~0u;
+            hipStream_t ps = nullptr;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+                hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d, 256) == hipSuccess) {
+                bool ok = hipMemsetAsync(d, 0, 256, ps) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(lds_drop_probe_kernel, dim3((unsigned)cus * 24u), dim3(64), 0, ps, d, 48);
+                    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ps) == hipSuccess && hipStreamSynchronize(ps) == hipSuccess;
+                }
+                if (ok && h == 0u) st = 1;
+            }
+            (void)hipGetLastError();
+            if (d) (void)hipFree(d);
+            if (ps) (void)hipStreamDestroy(ps);
+            g_lds_drop_state[dev].store(st, std::memory_order_release);
+        }
+    }
+    return st == 1;
+}
+
 // Work counters of the persistent lane decoder: a small per-device ring of 256-byte slots, one per launch in flight.  A slot comes
 // back into use after 64 further launches on that device, possibly on another stream, so each slot carries an event that its
 // user records after the last kernel that reads it: the next user's stream waits for that event before it zeroes the slot, and
@@ -637,16 +689,19 @@ int decoder_counter(int dev, hipStream_t stream, unsigned long long** out, Count
     if (dev < 0 || dev >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
     CounterRing& r = g_counter_ring[dev];
     void* mem = nullptr;
+    unsigned k = 0;
     {
+        // the slot's lock is taken while the ring's is still held: lz4hip_release_workspaces() (ring lock, then every slot's lock) can then
+        // neither free the ring between the two nor destroy the slot's event before this user has recorded it
         std::lock_guard<std::mutex> lk(r.mu);
         if (!r.mem) HIP_TRY(hipMalloc(&r.mem, 64 * 256));
         mem = r.mem;
+        k = r.next.fetch_add(1) & 63u;
+        lease.s = &r.slot[k];
+        lease.stream = stream;
+        lease.lock = std::unique_lock<std::mutex>(lease.s->mu);
+        if (!lease.s->done) HIP_TRY(hipEventCreateWithFlags(&lease.s->done, hipEventDisableTiming));
     }
-    const unsigned k = r.next.fetch_add(1) & 63u;
-    lease.s = &r.slot[k];
-    lease.stream = stream;
-    lease.lock = std::unique_lock<std::mutex>(lease.s->mu);
-    if (!lease.s->done) HIP_TRY(hipEventCreateWithFlags(&lease.s->done, hipEventDisableTiming));
     if (lease.s->used) HIP_TRY(hipStreamWaitEvent(stream, lease.s->done, 0));
     uint8_t* slot = (uint8_t*)mem + 256 * (size_t)k;
     HIP_TRY(hipMemsetAsync(slot, 0, 16, stream));                   // work counter + selected-block count
@@ -680,10 +735,20 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             // bit 4: input pieces are requested in the other iterations only, bit 5: sector input -- L holds a whole 64-byte sector
             // of the source and feeds the window one 32-byte half at a time)
             const int cfg = knob(kKnobDecoderRing) ? knob(kKnobDecoderRing) : kLane4Config;
-#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS, FE, IE, POL)                                                                    \
+            int dev = 0, cus = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            // ring rows stored twice (out-of-range LDS stores dropped by the hardware) only where this device's probe confirmed the rule
+            const bool wrapped = knob(kKnobDecoderWrappedStores) != 0 || !lds_drop_confirmed(dev);
+#define LZ4HIP_LAUNCH_LANE4_POL(RING, PIECE, FLUSH, FS, FE, IE, POL)                                                                \
             do {                                                                                                                \
                 if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, RING, PIECE, FLUSH, FS, FE, IE, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter);  \
                 else       hipLaunchKernelGGL((decode_lane4_kernel<false, RING, PIECE, FLUSH, FS, FE, IE, POL>), dim3(grid), dim3(64), 0, stream, d, lane_filter); \
+            } while (0)
+#define LZ4HIP_LAUNCH_LANE4(RING, PIECE, FLUSH, FS, FE, IE, POL)                                                                    \
+            do {                                                                                                                \
+                if (wrapped) LZ4HIP_LAUNCH_LANE4_POL(RING, PIECE, FLUSH, FS, FE, IE, (POL) | 32);                                   \
+                else         LZ4HIP_LAUNCH_LANE4_POL(RING, PIECE, FLUSH, FS, FE, IE, POL);                                          \
             } while (0)
 #define LZ4HIP_LANE4_CASE(CFG) case CFG: LZ4HIP_LAUNCH_LANE4((CFG) % 1000, ((CFG) / 1000 & 2) ? 32 : 64, ((CFG) / 1000 & 1) ? 128 : 64, ((CFG) / 1000 & 4) ? 1 : 2, ((CFG) / 1000 & 8) ? 2 : 1, ((CFG) / 1000 & 16) ? 2 : 1, ((CFG) / 1000 & 32) ? 16 : 0); break
             // Default configuration: TWO forms of the same kernel.  One block per lane under hardware dispatch is the faster one for
@@ -698,9 +763,6 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 constexpr int R_ = kLane4Config % 1000, P_ = (kLane4Config / 1000 & 2) ? 32 : 64, FU_ = (kLane4Config / 1000 & 1) ? 128 : 64,
                               FS_ = (kLane4Config / 1000 & 4) ? 1 : 2, FE_ = (kLane4Config / 1000 & 8) ? 2 : 1, IE_ = (kLane4Config / 1000 & 16) ? 2 : 1,
                               POL_ = (kLane4Config / 1000 & 32) ? 16 : 0;
-                int dev = 0, cus = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                 static std::atomic<int> per_cu_cached[64];
                 int per_cu = dev >= 0 && dev < 64 ? per_cu_cached[dev].load(std::memory_order_relaxed) : 0;
                 if (per_cu <= 0) {
@@ -722,17 +784,23 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                     hipLaunchKernelGGL(count_selected_kernel, dim3(cg), dim3(256), 0, stream, d, lane_filter, (unsigned*)(counter + 1));
                     HIP_TRY(hipGetLastError());
                 }
-                if (mode != 1) {
-                    if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
-                    else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
-                    HIP_TRY(hipGetLastError());
-                }
-                if (mode != 0) {
-                    unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
-                    if (knob(kKnobDecoderGroups) > 0 && (unsigned)knob(kKnobDecoderGroups) < pg) pg = (unsigned)knob(kKnobDecoderGroups);
-                    if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
-                    else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POL_>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
-                }
+                unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
+                if (knob(kKnobDecoderGroups) > 0 && (unsigned)knob(kKnobDecoderGroups) < pg) pg = (unsigned)knob(kKnobDecoderGroups);
+                auto both_forms = [&](auto pol_tag) -> int {
+                    constexpr int POLX = decltype(pol_tag)::value;
+                    if (mode != 1) {
+                        if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                        else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
+                        HIP_TRY(hipGetLastError());
+                    }
+                    if (mode != 0) {
+                        if (known) hipLaunchKernelGGL((decode_lane4_persistent_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                        else       hipLaunchKernelGGL((decode_lane4_persistent_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(pg), dim3(64), 0, stream, d, lane_filter, counter, gate, mode == 2 ? 2 : 0, threshold);
+                    }
+                    return 0;
+                };
+                const int rc2 = wrapped ? both_forms(std::integral_constant<int, POL_ | 32>{}) : both_forms(std::integral_constant<int, POL_>{});
+                if (rc2) return rc2;
             } else
             switch (cfg) {
             LZ4HIP_LANE4_CASE(kLane4Config);
@@ -745,6 +813,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             }
 #undef LZ4HIP_LANE4_CASE
 #undef LZ4HIP_LAUNCH_LANE4
+#undef LZ4HIP_LAUNCH_LANE4_POL
         }
 #ifdef LZ4HIP_TUNING_BUILD                                              /* the generations it replaced (tools/ab/), for same-box A/B runs */
         else if (gen == 2) {
@@ -1328,6 +1397,22 @@ const char* lz4hip_codec_name(void)
 
 int lz4hip_compressBound(int isize) { return isize + isize / 255 + 16; }
 
+// Which sources this binary was built from: lz4net_amd/build.py hashes csrc/ (the hash bench.py and the committed counter files are keyed on) and
+// passes it in; the marker string is also how build.py recognises a stale prebuilt library without loading it.
+#ifndef LZ4HIP_CSRC_SHA
+#define LZ4HIP_CSRC_SHA "unknown"
+#endif
+#ifdef LZ4HIP_TUNING_BUILD
+#define LZ4HIP_BUILD_KIND "+tuning"
+#else
+#define LZ4HIP_BUILD_KIND ""
+#endif
+const char* lz4hip_build_id(void)
+{
+    static const char marker[] = "LZ4HIP_BUILD_ID=" LZ4HIP_CSRC_SHA LZ4HIP_BUILD_KIND;
+    return marker + 16;
+}
+
 int lz4hip_dispatch_counts(uint64_t* counts, int n)
 {
     for (int k = 0; counts && k < n && k < LZ4HIP_K_COUNT; k++) counts[k] = g_dispatch[k].load(std::memory_order_relaxed);
@@ -1413,6 +1498,13 @@ int lz4hip_tuning_get(const char* name)
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
         std::lock_guard<std::mutex> lk(g_fast_ws[dev].mu);
         return name[13] == 'r' ? (int)(g_fast_slab[dev].probe * 1000.0) : (name[13] == 't' ? g_fast_slab[dev].tries : (int)g_fast_slab[dev].chunks.size());
+    }
+    // read-only: 1 if lane-mapped decodes on the current device store their ring rows twice (the device's probe confirmed that out-of-range LDS
+    // stores are dropped, and the knob decoder_wrapped_stores is 0), 0 if they run the wrapped-row instantiation.  Runs the probe if it has not run yet.
+    if (name && strcmp(name, "decoder_dual_store") == 0) {
+        int dev = 0;
+        if (ensure_device() || hipGetDevice(&dev) != hipSuccess) return 0;
+        return (lds_drop_confirmed(dev) && knob(kKnobDecoderWrappedStores) == 0) ? 1 : 0;
     }
     for (int k = 0; name && k < kKnobCount; k++)
         if (strcmp(name, kKnobInfo[k].name) == 0) return g_knob[k].load(std::memory_order_relaxed);

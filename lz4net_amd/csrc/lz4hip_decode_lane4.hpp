@@ -73,7 +73,9 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //   POL    cache policy of the loads (wv::vm_load16_pred): low two bits = far-match fetches, next two bits = input pieces;
 //          bit 4 (16): SECTOR INPUT -- L holds a whole aligned 64-byte sector (four loads, one request to the memory side) and feeds
 //          W one 32-byte half at a time (needs P == 32): the window and its select tree stay those of 32-byte pieces, but each
-//          sector of the source is fetched once instead of as two halves ~10 us apart (by then the first one's line has left the L2)
+//          sector of the source is fetched once instead of as two halves ~10 us apart (by then the first one's line has left the L2);
+//          bit 5 (32): ring rows are WRAPPED instead of stored twice -- no DS store ever leaves the allocation.  The library launches this
+//          instantiation on a device whose load-time probe (lds_drop_probe_kernel below) did not confirm that out-of-range stores are dropped
 template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0, class NEXT = NoNext>
 LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* src, int iend,
                                      uint8_t* dst, int oend, NEXT next = NEXT())
@@ -89,6 +91,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
     constexpr uint32_t kLdsBytes = lane4_lds_bytes(R);
     constexpr bool LS = (POL & 16) != 0;                             // L = one aligned 64-byte sector, consumed as two pieces
+    constexpr int kDual = (POL & 32) ? 0 : (LZ4HIP_DEC4_DUAL_STORE); // POL bit 5: ring rows WRAPPED, no store outside the allocation (the fallback of lz4hip_api.hip)
     static_assert(!LS || P == 32, "sector input feeds 32-byte pieces");
     constexpr int SK = LS ? 64 : P;                                  // alignment of the stream coordinates (what the loads are aligned to)
     constexpr int NW = 4 + P / 4, NL = LS ? 4 : P / 16;              // window dwords, loads per request
@@ -165,13 +168,13 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         const uint32_t sb_ = (uint32_t)op & 3u;                                                         \
         const uint32_t s_ = wv::alignbyte(0x08070605u, 0x04030201u, sb_ ^ 3u);                          \
         wv::lds_mskor(&L4_RING(oa), 0xFFFFFFFFu << (8u * sb_), wv::perm(d0_, 0u, s_));                  \
-        if (LZ4HIP_DEC4_DUAL_STORE) {                                                                   \
+        if (kDual) {                                                                                    \
             /* rows oa + 1 .. oa + 4, not wrapped: the rows past the end of the ring land in the flush records (rewritten before \
                they are next read) or outside the allocation (dropped), and the same rows seen from one ring size below land \
                where they belong or below address 0 (dropped) */                                        \
             const uint32_t ob_ = oa - kRingBytes;                                                       \
             const uint32_t w1_ = wv::perm(d1_, d0_, s_), w2_ = wv::perm(d2_, d1_, s_);                  \
-            if (LZ4HIP_DEC4_DUAL_STORE == 2) { /* two rows per LDS instruction */                       \
+            if (kDual == 2) { /* two rows per LDS instruction */                                        \
                 wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, oa, w1_, w2_);                           \
                 wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, ob_, w1_, w2_);                          \
                 if (FOUR_) {                                                                            \
@@ -576,6 +579,49 @@ LZ4HIP_DEVICE bool lane4_gate_open(const unsigned* gate, int gate_mode, unsigned
     if (gate_mode == 0) return true;
     const unsigned c = wv::uniform(*gate);
     return gate_mode == 1 ? c >= threshold : c < threshold;
+}
+
+// Load-time check of the hardware rule the dual ring stores rest on (L4_APPEND with kDual != 0): a DS store whose address lies outside
+// the workgroup's LDS allocation -- past its end, or "below zero" after a 32-bit wrap -- is DROPPED: no fault, and no byte of this or any
+// co-resident workgroup's allocation changes.  Every workgroup (one wavefront, the decoder's 12 800 bytes, twelve resident per CU) fills its
+// allocation with a pattern of its own, issues exactly the decoder's kinds of out-of-range stores (ds_write_b32 with an offset,
+// ds_write2st64_b32 with one or both rows outside, from `row` and from `row - ring size`), lingers so that its neighbours overlap with it,
+// and counts the pattern words that changed.  lz4hip_api.hip runs it once per device before the first lane-mapped decode; anything but
+// zero selects the wrapped-row instantiation (POL bit 5) for that device.  (tools/lds_out_of_range.hip is the stand-alone, longer form.)
+// NOTE: `lds` must be the ONLY __shared__ object of these kernels -- the dual stores assume that the ring starts at LDS address 0.
+__global__ void __launch_bounds__(64) lds_drop_probe_kernel(unsigned* errors, int rounds)
+{
+    constexpr uint32_t kBytes = lane4_lds_bytes(192), kRing = 64u * 192u, kWords = kBytes / 4u;
+    LZ4HIP_STATIC_LDS(lds, kBytes);
+    uint32_t* const s = (uint32_t*)lds;
+    const uint32_t lane = threadIdx.x, tag = 0x9E3779B9u * (blockIdx.x + 1u);
+    for (uint32_t i = lane; i < kWords; i += 64u) s[i] = tag ^ i;
+    wv::block_sync();
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t junk = 0xDEAD0000u | (uint32_t)r;
+        const uint32_t last = kRing - 256u + lane * 4u;              // the ring's last row: rows + 1 .. + 4 of an append from here
+        const uint32_t own = tag ^ (last >> 2);
+        // (a) from `row`: the rows past the ring land in the flush records (in range, rewritten below) or past the allocation (dropped)
+        wv::lds_store2_rows_drop<0, 3>(lds, kBytes, last, own, junk);      // row 0 in range, row + 3 = 256 bytes past the END of the allocation
+        wv::lds_store2_rows_drop<3, 4>(lds, kBytes, last, junk, junk);     // both past the end
+        wv::lds_store_drop<1024>(lds, kBytes, last, junk);
+        wv::lds_store_drop<768>(lds, kBytes, kBytes - 256u + lane * 4u, junk);
+        // (b) from `row - ring size` for rows that did not wrap: "negative" addresses
+        const uint32_t neg = lane * 4u - kRing;
+        wv::lds_store2_rows_drop<1, 2>(lds, kBytes, neg, junk, junk);
+        wv::lds_store2_rows_drop<3, 4>(lds, kBytes, neg + 2048u, junk, junk);
+        wv::lds_store_drop<768>(lds, kBytes, neg, junk);
+        wv::lds_store2_rows_drop<0, 48>(lds, kBytes, neg, junk, tag ^ lane);   // row 0 below zero (dropped), row 48 = this lane's dword of row 0 (in range)
+        // the flush records behind the ring take (a)'s in-range overshoot in the decoder; here they keep their pattern
+        wv::mem_sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_sleep(8);
+#endif
+    }
+    wv::block_sync();
+    unsigned bad = 0;
+    for (uint32_t i = lane; i < kWords; i += 64u) bad += s[i] != (tag ^ i) ? 1u : 0u;
+    if (bad) atomicAdd(errors, bad);
 }
 
 // One wavefront per workgroup; lane i of workgroup g decodes block g*64 + i.

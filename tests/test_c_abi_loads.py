@@ -143,3 +143,48 @@ def test_tuning_knobs_without_gpu():
     for name in ("encoder_slab_rate", "encoder_slab_tried", "encoder_slab_chunks"):
         assert _lib.tuning_get(name) == 0
         assert L.lz4hip_tuning_set(name.encode(), 1) == _lib.E_ARGUMENT
+
+
+def test_library_identifies_its_sources():
+    """lz4hip_build_id() = the hash of lz4net_amd/csrc/ the binary was compiled from (prebuilt .so files travel to the GPU box): it equals the tree's
+    hash after build(), the same string is found in the file without loading it (how build.is_stale() recognises a stale library by CONTENT),
+    a library whose marker names other sources is stale, and bench.py's csrc_sha() is that hash."""
+    import shutil
+    import sys
+    from lz4net_amd import _lib, build as hip_build
+    L = _lib.lib()
+    bid = L.lz4hip_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}(\+tuning)?", bid), bid
+    assert bid.split("+")[0] == hip_build.csrc_sha()
+    assert hip_build.built_id() == bid and not hip_build.is_stale()
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.csrc_sha() == hip_build.csrc_sha()
+    # a copy whose marker names other sources: recognised as stale
+    data = open(hip_build.SO, "rb").read()
+    marker = b"LZ4HIP_BUILD_ID=" + bid.split("+")[0].encode()
+    assert data.count(marker) >= 1
+    so_dir = os.path.dirname(hip_build.SO)
+    fake = os.path.join(so_dir, "liblz4hip.so.stale_test")
+    try:
+        with open(fake, "wb") as fh:
+            fh.write(data.replace(marker, b"LZ4HIP_BUILD_ID=" + b"0123456789abcdef"))
+        assert hip_build.built_id(fake) == "0123456789abcdef" + ("+tuning" if "+" in bid else "")
+        assert hip_build.built_id(fake) != hip_build.wanted_id()
+    finally:
+        if os.path.exists(fake):
+            os.remove(fake)
+    assert hip_build.built_id(os.path.join(so_dir, "no_such_library.so")) is None
+
+
+def test_decoder_store_knobs_without_gpu():
+    """decoder_wrapped_stores is an ordinary settable knob; its read-only twin decoder_dual_store cannot be set and, without a device to probe,
+    says 0 (the wrapped-row instantiation would run)."""
+    from lz4net_amd import _lib
+    L = _lib.lib()
+    prev = _lib.tuning_set("decoder_wrapped_stores", 1)
+    assert _lib.tuning_get("decoder_wrapped_stores") == 1
+    assert _lib.tuning_set("decoder_wrapped_stores", prev) == 1
+    assert L.lz4hip_tuning_set(b"decoder_dual_store", 1) == _lib.E_ARGUMENT
+    if L.lz4hip_device_count() == 0:
+        assert L.lz4hip_tuning_get(b"decoder_dual_store") == 0
