@@ -42,6 +42,14 @@
 #ifndef LZ4HIP_STAT
 #define LZ4HIP_STAT(slot, cond) ((void)0)   /* the emulator build counts lane-iterations per state (tools/emu_decoder_stats.py) */
 #endif
+// Section markers for the per-section instruction table of the compiled kernel (tools/isa_lane4_table.py builds with
+// -DLZ4HIP_SECTION_MARKERS: each marker becomes a comment line in the assembly listing; volatile asm statements -- most of this kernel's
+// selects, loads and stores -- keep their order relative to the markers).  Nothing in product builds.
+#ifdef LZ4HIP_SECTION_MARKERS
+#define LZ4HIP_SECTION(name) asm volatile("; @@SECTION " name)
+#else
+#define LZ4HIP_SECTION(name) ((void)0)
+#endif
 
 namespace lz4hip {
 
@@ -219,6 +227,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         // ================================ TOP ================================
         // ---- (T1) the input window: take the next piece in once the cursor has left the current one; the 16 bytes at the
         //      cursor; the 16 bytes at the source of the current near match ----
+        LZ4HIP_SECTION("T1a window refill");
         int d = ip + skew - wb;                                      // byte offset of the cursor in W: 0 .. 16 + P (+ 16 while a piece is awaited)
         {
             const bool no_more = wb + 16 + P >= in_total;            // W holds the last piece of the source
@@ -247,6 +256,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             wb += cross ? P : 0;
             d -= cross ? P : 0;
         }
+        LZ4HIP_SECTION("T1b cursor view (select tree + rotation)");
         const bool staged16 = d < P;                                 // the 16 bytes at the cursor lie in W (what lies past the source is never used)
         LZ4HIP_STAT(0, true); LZ4HIP_STAT(1, done == 0); LZ4HIP_STAT(2, (done == 0) & !staged16);
         uint32_t x0, x1, x2, x3;
@@ -268,6 +278,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             const uint32_t sx = L4_PHASE_SEL(d);
             x0 = wv::perm(t[1], t[0], sx); x1 = wv::perm(t[2], t[1], sx); x2 = wv::perm(t[3], t[2], sx); x3 = wv::perm(t[4], t[3], sx);
         }
+        LZ4HIP_SECTION("T1c near-match source rows");
         uint32_t v0, v1, v2, v3;
         {
             // row of output byte op - off: (op >> 2) - ((off - (op & 3) + 3) >> 2) rows back from oa
@@ -282,6 +293,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             v0 = wv::perm(r1, r0, sr); v1 = wv::perm(r2, r1, sr); v2 = wv::perm(r3, r2, sr); v3 = wv::perm(r4, r3, sr);
         }
 
+        LZ4HIP_SECTION("T2 cooperative flush");
         // ---- (T2) flush finished output, FU bytes at a time, FU / 16 lanes per unit: ALWAYS FS store instructions ----
         if constexpr (FLUSH) {
             const bool need = (done == 0) & (op - fl >= FU);
@@ -325,6 +337,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
                 fl += mine ? FU : 0;
             }
         }
+        LZ4HIP_SECTION("T3 chunk size");
         // ---- (T3) size of this iteration's chunk of the current copy (appended at the bottom) ----
         const bool room = op - fl <= R - 46;                         // this iteration's appends (<= 16 + 11 bytes + 19 of overshoot) stay clear of unflushed output
         const bool near = kind == kK4Near, lit = kind == kK4Lit;
@@ -337,6 +350,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         const int rem_after = rem - n;
         const int op_end = op + rem;                                 // where the current copy ends = where the parsed-ahead sequence's literals go
 
+        LZ4HIP_SECTION("T4 parse ahead");
         // ---- (T4) parse ahead: the next sequence's header (needs only the cursor) ----
         const bool may_parse = (pv == 0) & (final_seen == 0) & !(lit & (rem > 0)) & staged16;
         LZ4HIP_STAT(10, may_parse); LZ4HIP_STAT(11, (done == 0) & (pv != 0));
@@ -376,6 +390,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             p_flags = in_win ? 0 : (int)kF4Header;
             const int ip_fast = in_win ? p_after + (e2 ? 1 : 0) : ip + 1 + (e1 ? 1 : 0);
             if (trap) {
+                LZ4HIP_SECTION("T4x byte-wise parser (trap)");
                 // ---- byte-wise: token + literal length (lz4.c:844 / :957-961), or, in header position, offset + match length
                 //      (lz4.c:862-866 / :979-997); literals are always streamed from here, so the header gets its own parse ----
                 int err = 0, pos = ip;
@@ -431,9 +446,11 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
                 ip = ip_fast;
                 hdr = in_win ? 0 : 1;
             }
+            LZ4HIP_SECTION("T4 parse ahead");
             pv = 1;
         }
 
+        LZ4HIP_SECTION("T5 far fetch");
         // ---- (T5) far fetch for the chunk appended at the bottom of the NEXT iteration: ALWAYS one load instruction ----
         // continuation of the current far match, or the first 16 bytes of the parsed-ahead match if the current copy ends
         // in this iteration (the source of the chunk appended at output position p is p - off; a lane that could not append
@@ -451,6 +468,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             LZ4HIP_STAT(15, gready != 0); LZ4HIP_STAT(16, wv::sel(f_want & ~f_do, 1u, 0u) != 0u);
         }
 
+        LZ4HIP_SECTION("T6 input request");
         // ---- (T6) the next piece of input, once L is free: ALWAYS NL load instructions, each lane for itself ----
         if constexpr (INPUT) {
             const int lpos = wb + 16 + P;                            // aligned stream position of the piece L is for (sector input: a multiple of 64 whenever L is free)
@@ -468,6 +486,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         }
 
         // ================================ BOTTOM ================================
+        LZ4HIP_SECTION("B1 wait");
         // ---- (B1) the loads of the PREVIOUS iteration have landed (this iteration's kVm accesses stay in flight) ----
         wv::vm_wait_list<kVm>(usF, L);
         lvalid = us_pend ? 1 : lvalid;
@@ -484,6 +503,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         for (int bi = 0; bi < LZ4HIP_DEC4_BALLAST_LDS; bi++) wv::lds_store_drop<0>(lds, kLdsBytes, 0x80000000u + lane4, ballast);
 #endif
 #endif
+        LZ4HIP_SECTION("B3 chunk append");
         // ---- (B3) append the chunk ----
         {
             const bool far_src = kind == kK4Far;
@@ -503,6 +523,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             kind = rem == 0 ? (int)kK4None : kind;
         }
 
+        LZ4HIP_SECTION("B4 promote + literal append");
         // ---- (B4) promote the parsed-ahead sequence: its inline literals, then its copy becomes the current one ----
         {
             const bool promote = (rem == 0) & (pv != 0) & room;
@@ -524,6 +545,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             pv = promote ? 0 : pv;
         }
 
+        LZ4HIP_SECTION("B5 end of block + loop");
         // ---- (B5) end of block: write out the last bytes exactly ----
         if (final_run && rem == 0 && !pv && !done) {
             uint32_t qa = ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu));

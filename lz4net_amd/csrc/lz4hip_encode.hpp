@@ -15,6 +15,15 @@
 #pragma once
 #include "lz4hip_common.hpp"
 
+// Section timers of the wavefront encoder (tools/enc_wave_sections.hip defines these to s_memtime accumulators; nothing in product builds).
+#ifndef LZ4HIP_ENC_T0
+#define LZ4HIP_ENC_DECL() ((void)0)
+#define LZ4HIP_ENC_T0() ((void)0)
+#define LZ4HIP_ENC_T(slot) ((void)0)
+#define LZ4HIP_ENC_COUNT(slot, n) ((void)0)
+#define LZ4HIP_ENC_FLUSH() ((void)0)
+#endif
+
 namespace lz4hip {
 
 template <bool GENERIC> struct FastTable;
@@ -169,6 +178,7 @@ LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC
         }
         ip = (int)wv::readlane((uint32_t)p_next, 63);                // 64 probes without a match
         attempts += 64;
+        LZ4HIP_ENC_COUNT(4, 1);
     }
 }
 
@@ -282,11 +292,173 @@ tail:
     return op;
 }
 
+// ---- LZ4_compress64kCtx, second version (round 6): the sequence-dense path --------------------------------------------
+// encode_fast_block<false> above spends 238 wave-instructions on a sequence of fuzzer-style data (150 of them scalar;
+// profiles/r05/pmc_wave_kernels_512_blocks.json), and a lone wavefront issues one instruction per ~10 cycles: a block's latency IS its
+// instruction count.  Two thirds of such data's sequences are the reference's "test next position" case (lz4.c:739-751: zero literals, the
+// re-probe at ip hits), so that case gets a straight-line path of its own:
+//   * the 8 bytes at ip - 2 (both hash inputs) come out of a REGISTER WINDOW of the input -- lane l holds the dword at wbase + 4 l, three
+//     v_readlane_b32 and two scalar shifts give the unaligned qword -- instead of a global load and its round trip;
+//   * the candidate test A32(ref) == A32(ip) and the count of the match are ONE operation: 256 bytes of both sides (4 per lane, the ip
+//     side requested before the table is touched), xor, ballot, first differing lane: lane 0 differs = no match, else the length;
+//   * the whole sequence (token, <= 14 literals, offset) leaves in ONE predicated byte store, lane j writing byte j, once its lengths are
+//     known -- the reference writes the token first and ors the match length in later; the bytes are the same.
+// The search (wave_find_match, 64 probes per step), the catch-up and the rare shapes (long literal runs, length bytes, the end of the
+// block, limited output) are those of the first version, statement for statement.  Same bytes, same return values.
+struct FastSeq { int op; bool ok; };
+// One sequence: token + literal length bytes + ll literals from in[anchor..] + offset + match length bytes; mlen = the whole match (>= 4).
+// The limit tests are those of lz4.c:663 / :728 in the reference's order (and the two of the first version that stand for its stray writes).
+LZ4HIP_DEVICE FastSeq emit_fast_sequence(const uint8_t* in, uint8_t* out, int cap, int op, int anchor, int ll, uint32_t off, int mlen)
+{
+    const int lane = wv::lane();
+    const int extra = mlen - kMinMatch;
+    if (ll < 15 && extra < 15) {
+        // token, literals, offset: ll + 3 <= 17 bytes, lane j writes byte j.  (lz4.c:663: op + 1 + ll + (ll >> 8) > cap - 8 fails; what
+        // :728 tests afterwards, op + 3 + ll > cap - 6, is the same inequality for these lengths.)
+        if (op + 1 + ll > cap - 8) return FastSeq{ 0, false };
+        const uint32_t tok = ((uint32_t)ll << 4) | (uint32_t)extra;
+        if (lane < ll + 3) {
+            uint32_t v = tok;
+            if (lane >= 1 && lane <= ll) v = in[anchor + lane - 1];
+            if (lane > ll) v = lane == ll + 1 ? (off & 255u) : (off >> 8);
+            out[op + lane] = (uint8_t)v;
+        }
+        return FastSeq{ op + ll + 3, true };
+    }
+    int token_at = op++;
+    if (op + ll + (ll >> 8) > cap - 8) return FastSeq{ 0, false };                  // lz4.c:663
+    if (ll >= 15 && op + (ll - 15) / 255 + 1 + ll > cap) return FastSeq{ 0, false };
+    if (ll >= 15) op += put_length_bytes(out + op, ll - 15);
+    wave_copy(out + op, in + anchor, ll);
+    op += ll;
+    if (op + 2 > cap) return FastSeq{ 0, false };
+    if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
+    op += 2;
+    if (op + (extra >> 8) > cap - 6) return FastSeq{ 0, false };                    // lz4.c:728
+    if (extra >= 15 && op + (extra - 15) / 255 + 1 > cap) return FastSeq{ 0, false };
+    if (lane == 0) out[token_at] = (uint8_t)((ll >= 15 ? 0xF0u : (uint32_t)(ll << 4)) | (extra >= 15 ? 15u : (uint32_t)extra));
+    if (extra >= 15) op += put_length_bytes(out + op, extra - 15);
+    return FastSeq{ op, true };
+}
+
+LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, int cap, unsigned char* table_bytes, bool may_defer = false)
+{
+    typedef FastTable<false> T;
+    uint16_t* const table = (uint16_t*)table_bytes;
+    const int lane = wv::lane();
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    int ip = 0, anchor = 0, op = 0;
+    int sequences = 0, checked_at = 0;                                // (hand-over rule, see kDeferredResult)
+    LZ4HIP_ENC_DECL();
+
+    if (n >= kMinLength) {                                            // lz4.c:615
+        for (int k = lane * 16; k < kFastTableBytes; k += 64 * 16) {  // fresh zeroed table per block (lz4.c:583)
+            Vec16 z = { { 0, 0, 0, 0 } };
+            *(Vec16*)(table_bytes + k) = z;
+        }
+        wv::mem_sync();
+        // the register window: lane l holds in[wbase + 4 l .. + 4) (0 past the end); a qword at q comes out of it while 0 <= q - wbase <= 244
+        uint32_t win = 0;
+        int wbase = -(1 << 20);
+        ip = 1;                                                       // lz4.c:631: position 0 is never probed
+        for (;;) {
+            // ---- find a match: lz4.c:642-654, 64 probes of the skip schedule per step ----
+            int ref = 0;
+            LZ4HIP_ENC_T0();
+            if (!wave_find_match<false>(in, table, ip, ref, mflimit)) break;
+            LZ4HIP_ENC_T(0);
+            // ---- catch up: lz4.c:657 (the first 256 bytes of the forward count are requested before it, see the first version) ----
+            const uint32_t fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
+            int caught_up = 0;
+            {
+                const int room = ip - anchor, bound = room < ref ? room : ref;
+                const int back = bound > 0 ? wave_catch_up(in, ip, ref, bound) : 0;
+                ip -= back; ref -= back; caught_up = back;
+            }
+            // ---- literals, offset, match length: lz4.c:660-733 ----
+            {
+                const int mlen = kMinMatch + caught_up + wave_common_length(in, ip + kMinMatch + caught_up, ref + kMinMatch + caught_up, matchlimit, fwd_round);
+                const FastSeq e = emit_fast_sequence(in, out, cap, op, anchor, ip - anchor, (uint32_t)(ip - ref) & 0xFFFFu, mlen);
+                if (!e.ok) return 0;
+                op = e.op;
+                ip += mlen; anchor = ip;
+            }
+            LZ4HIP_ENC_T(1);
+            // ---- test next position: lz4.c:736-751, as long as it hits ----
+            for (;;) {
+                LZ4HIP_ENC_T0();
+                if (may_defer && (++sequences % kDeferCheckSequences) == 0) {
+                    if (ip - checked_at < kDeferCheckSequences * kDeferBytesPerSequence) return kDeferredResult;
+                    checked_at = ip;
+                }
+                if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
+                const bool wide = ip + 256 <= matchlimit;             // 256 bytes from ip may be read and counted (wave-uniform)
+                uint32_t a4 = 0;
+                if (wide) a4 = load_u32(in + ip + 4 * lane);          // the ip side of test + count, on its way while the table is looked up
+                // bytes ip-2 .. ip+5 (ip <= mflimit: inside the block) out of the window
+                const int q = ip - 2;
+                int rel = q - wbase;
+                if ((unsigned)rel > 244u) {
+                    wbase = q; rel = 0;
+                    const int pos = q + 4 * lane;
+                    win = pos + 4 <= n ? load_u32(in + pos) : 0u;
+                }
+                const int k = rel >> 2;
+                const uint32_t sh = ((uint32_t)rel & 3u) * 8u;
+                const uint32_t d0 = wv::readlane(win, k), d1 = wv::readlane(win, k + 1), d2 = wv::readlane(win, k + 2);
+                const uint32_t w_m2 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);     // bytes ip-2 .. ip+1
+                const uint32_t w_p2 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);     // bytes ip+2 .. ip+5
+                const uint32_t cur_word = (w_m2 >> 16) | (w_p2 << 16);                   // bytes ip .. ip+3
+                const uint32_t h2 = T::hash(w_m2), h = T::hash(cur_word);
+                table[h2] = (uint16_t)(ip - 2);                       // (every lane stores the same value: no lane mask to set up)
+                wv::mem_sync();
+                const int ref2 = (int)wv::uniform((uint32_t)table[h]);
+                table[h] = (uint16_t)ip;
+                int mlen;
+                if (wide) {
+                    const uint32_t diff = a4 ^ load_u32(in + ref2 + 4 * lane);
+                    const uint64_t stop = wv::ballot(diff != 0);
+                    if (stop & 1ull) { LZ4HIP_ENC_T(3); break; }      // A32(ref) != A32(ip)
+                    if (stop) {
+                        const int first = wv::ctz64(stop);
+                        mlen = first * 4 + (__builtin_ctz(wv::readlane(diff, first)) >> 3);
+                    } else {
+                        mlen = 256 + wave_common_length(in, ip + 256, ref2 + 256, matchlimit);
+                    }
+                } else {
+                    if (input_word(in, ref2) != cur_word) { LZ4HIP_ENC_T(3); break; }
+                    mlen = kMinMatch + wave_common_length(in, ip + kMinMatch, ref2 + kMinMatch, matchlimit);
+                }
+                const FastSeq e = emit_fast_sequence(in, out, cap, op, ip, 0, (uint32_t)(ip - ref2) & 0xFFFFu, mlen);   // zero-literal sequence (lz4.c:751)
+                if (!e.ok) return 0;
+                op = e.op;
+                ip += mlen; anchor = ip;
+                LZ4HIP_ENC_T(2);
+            }
+            anchor = ip++;                                            // lz4.c:754-755
+        }
+    }
+tail:
+    {   // ---- last literals: lz4.c:758-767 ----
+        const int run = n - anchor;
+        if (op + run + 1 + (run - 15 + 255) / 255 > cap) return 0;   // lz4.c:762
+        if (lane == 0) out[op] = (uint8_t)(run >= 15 ? 0xF0 : (run << 4));
+        op++;
+        if (run >= 15) op += put_length_bytes(out + op, run - 15);
+        wave_copy(out + op, in + anchor, run);
+        op += run;
+    }
+    LZ4HIP_ENC_FLUSH();
+    return op;
+}
+
 // One wavefront (= one workgroup of 64 threads) per block; 16 KiB of dynamic LDS per workgroup,
 // so up to 10 blocks are resident per CU.
 // flags: kEncodeOnlyGeneric: handle just the blocks of LZ4_64KLIMIT bytes and more; kEncodeMayDefer: blocks below
 // LZ4_64KLIMIT made of short sequences get kDeferredResult instead of being finished (a second launch takes them).
 enum EncodeKernelFlags { kEncodeOnlyGeneric = 1, kEncodeMayDefer = 2 };
+// V64K: which version of the 64k encoder runs (2 = encode_fast_block64k, the product; 1 = the first version, instantiated in tuning builds only: A/B runs)
+template <int V64K = 2>
 __global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int flags)
 {
     const int only_generic = flags & kEncodeOnlyGeneric;
@@ -299,9 +471,42 @@ __global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int flags)
     const uint8_t* src = batch_src(b, blk);
     uint8_t* dst = batch_dst(b, blk);
     int r;
-    if (n < k64kLimit) r = encode_fast_block<false>(src, n, dst, cap, lds, (flags & kEncodeMayDefer) != 0);      // lz4.c:783-785
+    if (n < k64kLimit) r = V64K == 2 ? encode_fast_block64k(src, n, dst, cap, lds, (flags & kEncodeMayDefer) != 0)          // lz4.c:783-785
+                                     : encode_fast_block<false>(src, n, dst, cap, lds, (flags & kEncodeMayDefer) != 0);
     else               r = encode_fast_block<true>(src, n, dst, cap, lds);
     if (wv::lane() == 0) b.result[blk] = r;
+}
+
+// The blocks the launch above handed over (result[] == kDeferredResult), taken from the BACK of the batch by a persistent grid of
+// wavefronts while the lane-per-block grid (lz4hip_encode_lane.hpp) takes them from the front: the two kernels run side by side on two
+// streams -- the lane mapping is bound by the device's rate of random sector read-modify-writes and needs no LDS, this one by a wavefront's
+// own latency and 16 KiB of LDS -- and each block goes to whichever claims it first (compare-and-swap on result[]).  `reach`: how many
+// blocks from the back this grid may look at (the batch size; tests pass less so that both kernels get work in an emulator that runs them
+// one after the other).  counter: zeroed by the host.
+constexpr int kBackClaimRun = 16;                                     // block indices per counter increment
+__global__ void __launch_bounds__(64) encode_fast_back_kernel(Batch b, unsigned long long* counter, long long reach)
+{
+    LZ4HIP_DYN_LDS(lds);
+    const int lane = wv::lane();
+    for (;;) {
+        long long k0 = 0;
+        if (lane == 0) k0 = (long long)atomicAdd(counter, (unsigned long long)kBackClaimRun);
+        k0 = (long long)wv::first_lane((uint64_t)k0);
+        if (k0 >= reach || k0 >= b.n_blocks) return;
+        for (int j = 0; j < kBackClaimRun; j++) {
+            const long long k = k0 + j;
+            if (k >= reach || k >= b.n_blocks) return;
+            const int64_t blk = b.n_blocks - 1 - k;
+            int mine = 0;
+            if (lane == 0 && b.result[blk] == kDeferredResult) mine = atomicCAS(&b.result[blk], kDeferredResult, kClaimedResult) == kDeferredResult ? 1 : 0;
+            if (!wv::first_lane((uint64_t)mine)) continue;
+            const int n = wv::uniform(batch_src_len(b, blk)), cap = wv::uniform(batch_dst_cap(b, blk));
+            // (only blocks below LZ4_64KLIMIT are ever handed over)
+            const int r = encode_fast_block64k(batch_src(b, blk), n, batch_dst(b, blk), cap, lds, false);
+            if (lane == 0) b.result[blk] = r;
+            wv::mem_sync();
+        }
+    }
 }
 
 }  // namespace lz4hip

@@ -243,6 +243,7 @@ inline bool took_part(const Lane& l, unsigned p, unsigned tag) { return l.slot_t
 
 // device atomics: lanes never run concurrently in the emulator
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
+template <class T> inline T atomicCAS(T* p, T expected, T desired) { T o = *p; if (o == expected) *p = desired; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 

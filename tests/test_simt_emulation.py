@@ -131,6 +131,44 @@ def test_encode_fast_limited_output(oracle, lane):
             assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
 
 
+def test_encode_fast64k_window_wide_count_and_single_store_paths(oracle):
+    """The second version of the 64k fast encoder (lz4hip_encode.hpp, encode_fast_block64k): its register window (re-based every ~244 bytes
+    and after every long match), the combined candidate test + 256-byte count (and its continuation past 256 equal bytes, and the byte-wise
+    form within 261 bytes of the end), the one-store sequence emit (<= 14 literals, match < 19) next to the general one -- on sizes around
+    every threshold, dense / sparse / periodic / long-run data, with exact and too-small output limits (return value and guard bytes)."""
+    rng = np.random.default_rng(606)
+    blocks = []
+    for n in list(range(13, 40)) + [255, 256, 257, 260, 261, 262, 263, 268, 269, 270, 300, 511, 512, 513, 517, 518, 519, 777, 1200, 5000, 33333, 65536, 65546]:
+        for dist in (2, 3):
+            blocks.append(oracle.gen(dist, 600 + n, n, 1, n)[0][:n])
+    for n in (300, 1000, 4000, 20000):
+        blocks.append(rng.integers(0, 2, n, dtype=np.uint8))                                   # long runs of near-matches
+        blocks.append(np.tile(rng.integers(0, 256, 7, dtype=np.uint8), n // 7 + 1)[:n])       # period 7: one match of n - 12 bytes
+        a = np.tile(rng.integers(0, 256, 300, dtype=np.uint8), n // 300 + 1)[:n].copy()       # period 300 with a few damaged bytes: matches > 256
+        a[rng.integers(0, n, max(n // 900, 1))] ^= 0x55
+        blocks.append(a)
+        b = rng.integers(0, 256, n, dtype=np.uint8)                                            # incompressible with islands of copies
+        for _ in range(n // 200):
+            src, ln, dstp = int(rng.integers(0, n - 40)), int(rng.integers(4, 40)), int(rng.integers(40, n - 40))
+            b[dstp:dstp + ln] = b[src:src + ln]
+        blocks.append(b)
+    want = [oracle.compress(a) for a in blocks]
+    res, dst = emu.encode(blocks)
+    for i, (a, w) in enumerate(zip(blocks, want)):
+        assert res[i] == len(w), (i, a.size, res[i], len(w))
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+        assert (dst[i, compress_bound(a.size):] == 0xA5).all()
+    for delta in (0, -1, -3, -9):
+        caps = [max(len(w) + delta, 0) for w in want]
+        res, dst = emu.encode(blocks, caps=caps)
+        for i, a in enumerate(blocks):
+            r = oracle.compress_raw(a, caps[i])[0]
+            assert res[i] == r, (i, a.size, delta, res[i], r)
+            assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
+            if r > 0:
+                assert np.array_equal(dst[i, :r], want[i]), (i, delta)
+
+
 def test_encode_fast_two_launches_hand_over(oracle):
     """Default dispatch of a large batch: the wavefront mapping hands blocks made of short sequences over to the lane
     mapping (kDeferredResult) and finishes the others; every block ends up with the reference's bytes whoever encoded it."""
@@ -181,6 +219,32 @@ def test_checksum_and_compare(oracle):
     b[1, 17] ^= 1; b[4, 4999] ^= 0x80; b[4, 4998] ^= 0x80
     assert emu.compare(a, a, [5000] * 5) == 0
     assert emu.compare(a, b, [5000] * 5) == 3
+
+
+def test_encode_fast_shared_hand_over(oracle):
+    """Round 6: the blocks the first launch hands over are claimed (compare-and-swap on result[]) by two kernels -- the persistent wavefront grid
+    from the back of the batch, the lane grid from the front.  Every block ends up with the reference's bytes whichever kernel encoded
+    it, each block is encoded exactly once, and both kernels get work (the emulator runs them one after the other: `reach` bounds the first)."""
+    blocks = []
+    for i in range(24):
+        blocks.append(oracle.gen(2, 40 + i, i, 1, 30000 + 1500 * i)[0][:30000 + 1500 * i])    # dense: handed over
+    blocks += [oracle.gen(1, 9, 0, 1, 65536)[0], oracle.gen(0, 9, 0, 1, 65536)[0], oracle.gen(3, 9, 1, 1, 65536)[0], oracle.gen(2, 9, 2, 1, 65547)[0][:65547]]
+    blocks += [oracle.gen(2, 90 + i, i, 1, 65536)[0] for i in range(4)]
+    want = [oracle.compress(a) for a in blocks]
+    res, dst, who = emu.encode_shared(blocks, reach=12)
+    for i, (a, w) in enumerate(zip(blocks, want)):
+        assert res[i] == len(w), (i, a.size, res[i], len(w), who[i])
+        assert np.array_equal(dst[i, :res[i]], w), (i, a.size, who[i])
+        assert (dst[i, compress_bound(a.size):] == 0xA5).all()
+    assert set(who.tolist()) == {0, 1, 2}, who.tolist()
+    assert (who[-12:] != 2).all() and (who[:len(blocks) - 12] != 1).all()       # the wavefront grid stayed within its reach
+    # limited output through the shared path: same return values as the reference
+    caps = [max(len(w) - (i % 3), 0) for i, w in enumerate(want)]
+    res, dst, who = emu.encode_shared(blocks, reach=len(blocks), caps=caps)
+    for i, a in enumerate(blocks):
+        r = oracle.compress_raw(a, caps[i])[0]
+        assert res[i] == r, (i, res[i], r, who[i])
+        assert (dst[i, caps[i]:] == 0xA5).all(), (i, "wrote past the capacity")
 
 
 @pytest.mark.parametrize("lane", [False, True, "conv"], ids=["wave-per-block", "lane-per-block", "lane-per-block-convergent"])
