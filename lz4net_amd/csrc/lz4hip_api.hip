@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobEncoderShare, kKnobDecoderWrappedStores, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobDecoderWrappedStores, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -67,7 +67,6 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
-    { "encoder_share", "LZ4HIP_ENCODER_SHARE", false },               // fast encode of a large batch: 0 default = the blocks the first launch hands over are shared by the lane-per-block grid (from the front) and a persistent wavefront-per-block grid (from the back) running side by side; 1 = the lane-per-block grid alone (rounds 2-5)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
 std::atomic<int> g_knob[kKnobCount];
@@ -397,30 +396,6 @@ struct HcPipe {
 };
 HcPipe g_hc_pipe[64];
 
-// Side stream and events of the shared fast-encode launch (one set per device, created on first use; the workspace lease serialises its users).
-struct FastPipe {
-    bool ready = false;
-    hipStream_t side = nullptr;
-    hipEvent_t handed = nullptr, done = nullptr;
-    int init()
-    {
-        if (ready) return 0;
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&handed, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        ready = true;
-        return 0;
-    }
-    void release()
-    {
-        if (side) { (void)hipStreamDestroy(side); side = nullptr; }
-        if (handed) { (void)hipEventDestroy(handed); handed = nullptr; }
-        if (done) { (void)hipEventDestroy(done); done = nullptr; }
-        ready = false;
-    }
-};
-FastPipe g_fast_pipe[64];
-
 int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
 {
     if (b->n_blocks == 0) return 0;
@@ -471,40 +446,11 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
         }
         if (pick != 'w') {
             lease.queued = true;
-            // Both launches ('a'): the blocks handed over are SHARED -- the lane-per-block grid claims them from the front of the batch, a persistent
-            // grid of wavefronts (encode_fast_back_kernel) from its back, side by side on two streams: the first is bound by the device's
-            // rate of random sector read-modify-writes and uses no LDS, the second by a wavefront's latency and 16 KiB of LDS each, so their rates add
-            // (D2 at 2^20 blocks: 53 GB/s alone, see profiles/r06).  Knob encoder_share = 1: the lane-per-block grid alone.
-            const bool share = pick == 'a' && knob(kKnobEncoderShare) != 1;
-            FastPipe* fp = nullptr;
-            if (share) {
-                int dev = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                fp = &g_fast_pipe[dev];
-                int rc = fp->init();
-                if (rc) return rc;
-                lease.side.assign(1, fp->side);
-            }
-            HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));                  // +0: the lane grid's block counter, +64: the wavefront grid's
-            if (share) {
-                HIP_TRY(hipEventRecord(fp->handed, stream));
-                HIP_TRY(hipStreamWaitEvent(fp->side, fp->handed, 0));
-            }
+            HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
             hipLaunchKernelGGL(encode_fast_lane_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d,
-                               (unsigned long long*)ws, (uint8_t* const*)((uint8_t*)ws + 256), slab_tpc, pick == 'a' ? (share ? 2 : 1) : 0);
+                               (unsigned long long*)ws, (uint8_t* const*)((uint8_t*)ws + 256), slab_tpc, pick == 'a' ? 1 : 0);
             HIP_TRY(hipGetLastError());
             count_dispatch(LZ4HIP_K_ENCODE_LANE);
-            if (share) {
-                int dev = 0, cus = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                const unsigned back_groups = (unsigned)cus * 10u;         // what 16 KiB of LDS per wavefront lets a CU hold
-                hipLaunchKernelGGL(encode_fast_back_kernel, dim3(back_groups), dim3(64), kFastTableBytes, fp->side, d,
-                                   (unsigned long long*)((uint8_t*)ws + 64), (long long)d.n_blocks);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(fp->done, fp->side));
-                HIP_TRY(hipStreamWaitEvent(stream, fp->done, 0));        // the caller's stream ends up behind both grids
-            }
             int rc = lease_end(lease, stream);
             if (rc) return rc;
         }
@@ -1491,10 +1437,6 @@ int lz4hip_release_workspaces(void)
             if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
             g_fast_slab[dev].release();
             w.busy = false;
-        }
-        if (pool == g_fast_ws && g_fast_pipe[dev].ready) {           // (the shared fast-encode launch's side stream and events hang off the same lease)
-            if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));
-            g_fast_pipe[dev].release();
         }
         if (pool == g_hc_ws && g_hc_pipe[dev].ready) {               // (the sub-chunk pipeline's streams and events hang off the LZ4HC lease)
             if (w.busy && w.last) HIP_TRY(hipEventSynchronize(w.last));

@@ -27,10 +27,6 @@ constexpr int kFastTableBytes = 16384;  // u16[8192] (64k variant) or u32[4096] 
 // block whose sequences come thick and fast over to the lane-per-block launch by leaving this value in result[]
 // (never a valid return value: sizes are >= 0, error codes > INT32_MIN).
 constexpr int32_t kDeferredResult = INT32_MIN;
-// ... and a block handed over is then CLAIMED (atomic compare-and-swap of result[] from kDeferredResult) by whichever of the two kernels that
-// share the handed-over blocks gets to it first: the lane-per-block grid from the front of the batch, a persistent wavefront-per-block grid
-// from its back (lz4hip_api.hip launch_encode; round 6).
-constexpr int32_t kClaimedResult = INT32_MIN + 1;
 constexpr int kDeferCheckSequences = 16;   // every 16 sequences ...
 constexpr int kDeferBytesPerSequence = 64;  // ... the block is handed over if they covered less than 16 x 64 input bytes
 

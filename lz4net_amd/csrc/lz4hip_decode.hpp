@@ -38,6 +38,14 @@
 #ifndef LZ4HIP_STAT_ADD
 #define LZ4HIP_STAT_ADD(slot, n) ((void)0)
 #endif
+// Section timers of the wavefront decoder (tools/dec_wave_sections.hip defines these to s_memtime accumulators; nothing in product builds).
+#ifndef LZ4HIP_DEC_T0
+#define LZ4HIP_DEC_DECL() ((void)0)
+#define LZ4HIP_DEC_T0() ((void)0)
+#define LZ4HIP_DEC_T(slot) ((void)0)
+#define LZ4HIP_DEC_ADD(slot, n) ((void)0)
+#define LZ4HIP_DEC_FLUSH() ((void)0)
+#endif
 
 namespace lz4hip {
 
@@ -171,7 +179,9 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
     // the last one (lz4.c:851 / :965) nor run into the end of the output (:893 / :1024) nor read past the source.
     const int o_safe = KNOWN ? oend - 28 : oend - 32;
     const int i_safe = KNOWN ? iend - 5 : iend - 11;
+    LZ4HIP_DEC_DECL();
     for (;;) {
+        LZ4HIP_DEC_T0();
         if (burst_skip > 0) burst_skip--;
         else if (op <= o_burst && ip <= i_burst) {
             win.need(ip, 96);
@@ -238,13 +248,15 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                     if (live) { dst[op + lane] = (uint8_t)val; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)val; }
                     wv::mem_sync();
                     LZ4HIP_STAT(20, lane == 0); LZ4HIP_STAT_ADD(21, lane == 0 ? wv::popc64(tok_m) : 0); LZ4HIP_STAT_ADD(22, lane == 0 ? rounds : 0); (void)rounds;
+                    LZ4HIP_DEC_ADD(4, wv::popc64(tok_m)); LZ4HIP_DEC_ADD(5, rounds);
                     ip += s_tok; op += tot;
                     burst_done = true;
                     burst_fail = 0;
                     if (hit_other) burst_skip = 1;                   // the next sequence is known to need the general path
                 }
             }
-            if (burst_done) continue;
+            if (burst_done) { LZ4HIP_DEC_T(0); continue; }
+            LZ4HIP_DEC_T(1);
             LZ4HIP_STAT(23, lane == 0);
             burst_fail = burst_fail < 5 ? burst_fail + 1 : 5;       // no run of short sequences here: back off, 1, 2, 4 .. 32 sequences
             burst_skip = 1 << burst_fail >> 1;
@@ -281,6 +293,7 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                     wv::mem_sync();
                     LZ4HIP_STAT(24, lane == 0);
                     ip += 3 + tll; op = t_lit_end + t_ml;
+                    LZ4HIP_DEC_T(2);
                     continue;
                 }
             }
@@ -301,6 +314,7 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         if (last) {
             if (KNOWN) { if (lit_end != oend) return -ip; if (ip + ll > iend) return -ip; }
             else       { if (lit_end > oend) return -ip; if (ip + ll != iend) return -ip; }
+            LZ4HIP_DEC_FLUSH();
             wave_copy(dst + op, src + ip, ll);
             return KNOWN ? ip + ll : lit_end;
         }
@@ -360,6 +374,7 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         }
         wv::mem_sync();
         ip = p; op = match_end;
+        LZ4HIP_DEC_T(3);
     }
 }
 

@@ -477,36 +477,4 @@ __global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int flags)
     if (wv::lane() == 0) b.result[blk] = r;
 }
 
-// The blocks the launch above handed over (result[] == kDeferredResult), taken from the BACK of the batch by a persistent grid of
-// wavefronts while the lane-per-block grid (lz4hip_encode_lane.hpp) takes them from the front: the two kernels run side by side on two
-// streams -- the lane mapping is bound by the device's rate of random sector read-modify-writes and needs no LDS, this one by a wavefront's
-// own latency and 16 KiB of LDS -- and each block goes to whichever claims it first (compare-and-swap on result[]).  `reach`: how many
-// blocks from the back this grid may look at (the batch size; tests pass less so that both kernels get work in an emulator that runs them
-// one after the other).  counter: zeroed by the host.
-constexpr int kBackClaimRun = 16;                                     // block indices per counter increment
-__global__ void __launch_bounds__(64) encode_fast_back_kernel(Batch b, unsigned long long* counter, long long reach)
-{
-    LZ4HIP_DYN_LDS(lds);
-    const int lane = wv::lane();
-    for (;;) {
-        long long k0 = 0;
-        if (lane == 0) k0 = (long long)atomicAdd(counter, (unsigned long long)kBackClaimRun);
-        k0 = (long long)wv::first_lane((uint64_t)k0);
-        if (k0 >= reach || k0 >= b.n_blocks) return;
-        for (int j = 0; j < kBackClaimRun; j++) {
-            const long long k = k0 + j;
-            if (k >= reach || k >= b.n_blocks) return;
-            const int64_t blk = b.n_blocks - 1 - k;
-            int mine = 0;
-            if (lane == 0 && b.result[blk] == kDeferredResult) mine = atomicCAS(&b.result[blk], kDeferredResult, kClaimedResult) == kDeferredResult ? 1 : 0;
-            if (!wv::first_lane((uint64_t)mine)) continue;
-            const int n = wv::uniform(batch_src_len(b, blk)), cap = wv::uniform(batch_dst_cap(b, blk));
-            // (only blocks below LZ4_64KLIMIT are ever handed over)
-            const int r = encode_fast_block64k(batch_src(b, blk), n, batch_dst(b, blk), cap, lds, false);
-            if (lane == 0) b.result[blk] = r;
-            wv::mem_sync();
-        }
-    }
-}
-
 }  // namespace lz4hip

@@ -252,8 +252,7 @@ tail:
 // contiguous 8 GiB allocation, 25-27 G when it is spread (tools/microbench_random_sectors*.hip, profiles/r04/random_sectors_*.txt; the
 // "two rates" of this encoder, 44-46 and 53-54 GB/s, were whether its one allocation happened to straddle such a boundary).  The host
 // side builds a few candidate sets of chunks, measures each with slab_probe_kernel and keeps the fastest (launch_encode).
-// only_deferred != 0: just the blocks the wavefront-per-block launch handed over (result[] == kDeferredResult); 2: ... and each of them only
-// after claiming it (compare-and-swap to kClaimedResult) -- encode_fast_back_kernel (lz4hip_encode.hpp) works through the same blocks from the other end.
+// only_deferred != 0: just the blocks the wavefront-per-block launch handed over (result[] == kDeferredResult).
 __global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned long long* counter, uint8_t* const* chunks, unsigned tables_per_chunk, int only_deferred)
 {
     const unsigned g = blockIdx.x * 64u + threadIdx.x;
@@ -263,7 +262,6 @@ __global__ void __launch_bounds__(64) encode_fast_lane_kernel(Batch b, unsigned 
         const int64_t blk = (int64_t)atomicAdd(counter, 1ull);
         if (blk >= b.n_blocks) return;
         if (only_deferred && b.result[blk] != kDeferredResult) continue;
-        if (only_deferred == 2 && atomicCAS(&b.result[blk], kDeferredResult, kClaimedResult) != kDeferredResult) continue;
         const int n = batch_src_len(b, blk), cap = batch_dst_cap(b, blk);
         const uint8_t* src = batch_src(b, blk);
         uint8_t* dst = batch_dst(b, blk);

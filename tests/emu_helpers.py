@@ -132,23 +132,6 @@ def encode_two_launches(blocks, caps=None):
     return res, dst, deferred
 
 
-def encode_shared(blocks, reach, caps=None):
-    """launch_encode's default for large batches since round 6: the wavefront mapping with the hand-over rule, then the handed-over blocks
-    shared between the persistent wavefront grid (from the back, at most `reach` blocks far) and the lane grid (the rest).
-    Returns (result, dst, who) -- who[i]: 0 first launch, 1 wavefront grid from the back, 2 lane grid."""
-    src, sl = pack(blocks)
-    if caps is None:
-        caps = [len(b) + len(b) // 255 + 16 for b in blocks]
-    caps = np.array(caps, np.int32)
-    ds = max(int(caps.max()), 1) + 64
-    dst = np.full((len(blocks), ds), 0xA5, np.uint8)
-    res = np.zeros(len(blocks), np.int32)
-    who = np.zeros(len(blocks), np.int32)
-    lib().emu_encode_fast_shared(_p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res),
-                                 C.c_int64(len(blocks)), C.c_int64(reach), _p(who))
-    return res, dst, who
-
-
 def synth(dist, seed, first_block, n, length, stride=None, block_step=1):
     stride = length if stride is None else stride
     out = np.zeros((n, max(stride, 1)), np.uint8)

@@ -180,30 +180,6 @@ void emu_encode_fast_two_launches(const uint8_t* src, int64_t src_stride, const 
     simt::launch(dim3(1), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, cp, 64u, 1); });
 }
 
-// The three launches of a large batch since round 6 (launch_encode, 'a' with shared hand-over): the wavefront mapping with the hand-over
-// rule, then -- side by side on the device, one after the other here -- the persistent wavefront grid claiming handed-over blocks from
-// the back (it may look at the last `reach` blocks) and the lane grid claiming the rest from the front.  who[i]: 0 finished by the first
-// launch, 1 by the wavefront grid from the back, 2 by the lane grid.
-void emu_encode_fast_shared(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
-                            int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int64_t reach, int32_t* who)
-{
-    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
-    simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, kEncodeMayDefer); });
-    for (int64_t i = 0; i < n; i++) who[i] = result[i] == kDeferredResult ? -1 : 0;
-    static std::vector<uint8_t> ws;
-    ws.assign(256 + (size_t)64 * kLaneTableBytes, 0x5A);
-    memset(ws.data(), 0, 256);
-    unsigned long long* back_counter = (unsigned long long*)(ws.data() + 64);
-    simt::launch(dim3(2), dim3(64), kFastTableBytes, [=] { encode_fast_back_kernel(b, back_counter, (long long)reach); });
-    for (int64_t i = 0; i < n; i++) if (who[i] == -1 && result[i] != kDeferredResult) who[i] = 1;
-    unsigned long long* counter = (unsigned long long*)ws.data();
-    static uint8_t* one_chunk[1];
-    one_chunk[0] = ws.data() + 256;
-    uint8_t* const* cp = one_chunk;
-    simt::launch(dim3(1), dim3(64), 0, [=] { encode_fast_lane_kernel(b, counter, cp, 64u, 2); });
-    for (int64_t i = 0; i < n; i++) if (who[i] == -1) who[i] = 2;
-}
-
 #ifdef LZ4HIP_HAVE_HC
 void emu_encode_hc_lane(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
                         int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups, int heads32)

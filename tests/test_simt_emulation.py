@@ -221,32 +221,6 @@ def test_checksum_and_compare(oracle):
     assert emu.compare(a, b, [5000] * 5) == 3
 
 
-def test_encode_fast_shared_hand_over(oracle):
-    """Round 6: the blocks the first launch hands over are claimed (compare-and-swap on result[]) by two kernels -- the persistent wavefront grid
-    from the back of the batch, the lane grid from the front.  Every block ends up with the reference's bytes whichever kernel encoded
-    it, each block is encoded exactly once, and both kernels get work (the emulator runs them one after the other: `reach` bounds the first)."""
-    blocks = []
-    for i in range(24):
-        blocks.append(oracle.gen(2, 40 + i, i, 1, 30000 + 1500 * i)[0][:30000 + 1500 * i])    # dense: handed over
-    blocks += [oracle.gen(1, 9, 0, 1, 65536)[0], oracle.gen(0, 9, 0, 1, 65536)[0], oracle.gen(3, 9, 1, 1, 65536)[0], oracle.gen(2, 9, 2, 1, 65547)[0][:65547]]
-    blocks += [oracle.gen(2, 90 + i, i, 1, 65536)[0] for i in range(4)]
-    want = [oracle.compress(a) for a in blocks]
-    res, dst, who = emu.encode_shared(blocks, reach=12)
-    for i, (a, w) in enumerate(zip(blocks, want)):
-        assert res[i] == len(w), (i, a.size, res[i], len(w), who[i])
-        assert np.array_equal(dst[i, :res[i]], w), (i, a.size, who[i])
-        assert (dst[i, compress_bound(a.size):] == 0xA5).all()
-    assert set(who.tolist()) == {0, 1, 2}, who.tolist()
-    assert (who[-12:] != 2).all() and (who[:len(blocks) - 12] != 1).all()       # the wavefront grid stayed within its reach
-    # limited output through the shared path: same return values as the reference
-    caps = [max(len(w) - (i % 3), 0) for i, w in enumerate(want)]
-    res, dst, who = emu.encode_shared(blocks, reach=len(blocks), caps=caps)
-    for i, a in enumerate(blocks):
-        r = oracle.compress_raw(a, caps[i])[0]
-        assert res[i] == r, (i, res[i], r, who[i])
-        assert (dst[i, caps[i]:] == 0xA5).all(), (i, "wrote past the capacity")
-
-
 @pytest.mark.parametrize("lane", [False, True, "conv"], ids=["wave-per-block", "lane-per-block", "lane-per-block-convergent"])
 def test_encode_hc_bit_exact(oracle, lane):
     # LZ4HC: several blocks per persistent workgroup (stale-state check), 16- and 32-bit heads

@@ -1,4 +1,4 @@
-"""Fast encode of a large batch: the blocks the first launch hands over go to the lane-per-block grid alone (knob encoder_share = 1, rounds 2-5)
+"""(Experiment NOT kept: needs tools/ab/encoder_shared_handover.patch applied -- profiles/r06/encoder_shared_handover_ab.txt.)  Fast encode of a large batch: the blocks the first launch hands over go to the lane-per-block grid alone (knob encoder_share = 1, rounds 2-5)
 or are shared between it and a persistent wavefront grid working from the back of the batch (0, default).  Same process, same batches:
 kernel time by HIP events (best of 2), compressed lengths and checksums compared.
 usage: python tools/enc_shared_handover_ab.py [dists] [batch sizes]"""
