@@ -98,7 +98,8 @@ typedef struct lz4hip_batch {
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream);
 int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream);
 
-/* Host-resident batches: stages through device memory (H2D, kernels, D2H) and synchronises. */
+/* Host-resident batches: stages through device memory (H2D, kernels, D2H) and synchronises.  Batches of >= 8192 blocks (not LZ4HC) are cut
+ * round-robin over two staging pipelines on the current device, each on a persistent worker thread of the library (knob host_workers). */
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode);
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
 
@@ -157,6 +158,11 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 1 = the first candidate, unmeasured).  Read-only through lz4hip_tuning_get: "encoder_slab_rate" (what the
  *                                 current device's slab measured, 1000 x G probe steps per second; 0 = none / unmeasured), "encoder_slab_tried" (candidates built),
  *                                 "encoder_slab_chunks" (separate allocations the slab in use consists of)
+ *   "host_workers"               [LZ4HIP_HOST_WORKERS]  host-pointer batches of >= 8192 blocks on ONE device (lz4hip_*_batch_host; not LZ4HC) run as this many staging
+ *                                 pipelines that share the device -- the persistent workers of the *_multi entry points, block i -> worker i mod k -- so that one pipeline's
+ *                                 kernels and copies fill the other's gaps (0 = default 2; 1 = the calling thread's own pipeline alone; at most 8)
+ *   "encoder_wave_version"       [LZ4HIP_ENCODER_WAVE_VERSION]  wavefront-mapped fast encoder, blocks below LZ4_64KLIMIT: 0 = default 2 (encode_fast_block64k, round 6);
+ *                                 1 = the first version (exists in -DLZ4HIP_TUNING_BUILD libraries only: A/B runs)
  *   "decoder_wrapped_stores"     [LZ4HIP_DECODER_WRAPPED_STORES]  lane decoder: its default instantiation stores every ring row at `row` and at `row - ring size`
  *                                 and relies on gfx950 dropping the LDS store that falls outside the workgroup's allocation; the library CHECKS that rule once per
  *                                 device before the first lane-mapped decode (a ~1 ms probe launch) and uses the instantiation that wraps its rows instead (same bytes,

@@ -55,6 +55,8 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.environ.get("LZ4HIP_KEEP_LIBRARY") and os.path.exists(SO):
+        return SO                                                     # A/B runs copy a prebuilt VARIANT over the library (tools/r06/build_variants.sh): use it as it is
     if force or is_stale():
         if not os.path.exists(HIPCC):
             raise RuntimeError(f"{HIPCC} not found and {SO} is missing or stale (library {built_id()}, sources {wanted_id()}): cannot build the gfx950 library")

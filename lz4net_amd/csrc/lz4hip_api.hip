@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobDecoderWrappedStores, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobHostWorkers, kKnobDecoderWrappedStores, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -67,6 +67,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
+    { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2; 1 = the calling thread's pipeline alone, rounds 2-5)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
 std::atomic<int> g_knob[kKnobCount];
@@ -1255,7 +1256,7 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
 // (The "logical_devices" knob makes N workers out of fewer devices, wrapping around: how the threaded path is tested on
 // a one-GPU box.)
 template <class Run>
-int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run, int64_t slice_hint = 0)
+int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint64_t device_mask, Run run, int64_t slice_hint = 0, int workers_on_one_device = 0)
 {
     int rc = check_batch(hb);
     if (rc) return rc;
@@ -1265,7 +1266,7 @@ int run_host_batch_multi(const lz4hip_batch_t* hb, bool dst_len_is_result, uint6
     for (int d = 0; d < visible && d < 64; d++)
         if (device_mask == 0 || ((device_mask >> d) & 1ull)) devs.push_back(d);
     if (devs.empty()) return fail(LZ4HIP_E_ARGUMENT, "device_mask selects no visible device");
-    const int logical = knob(kKnobLogicalDevices);
+    const int logical = workers_on_one_device > 0 ? workers_on_one_device : knob(kKnobLogicalDevices);
     if (logical > 0) {
         const std::vector<int> base = devs;
         devs.clear();
@@ -1533,14 +1534,35 @@ int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, v
     return launch_decode(b, known_output_size, (hipStream_t)stream);
 }
 
+// A single-device host-pointer batch of kHostWorkersMinBlocks blocks or more runs as TWO staging pipelines on the same device (the persistent
+// workers of the multi-device path, block i -> worker i mod 2): one pipeline's kernels and copies fill the gaps of the other's -- a 16 384-block
+// D2 decode 23.6 -> 33.5 GB/s on the driver's box of round 5/6 (profiles/r06/bench_driver_style_call1.json, host_pointer_batch_multi_device).
+// Knob host_workers: 1 = the calling thread's pipeline alone.
+constexpr int64_t kHostWorkersMinBlocks = 8192;
+int host_workers_for(const lz4hip_batch_t* b, int mode_is_hc)
+{
+    if (!b || b->n_blocks < kHostWorkersMinBlocks || mode_is_hc) return 1;
+    const int k = knob(kKnobHostWorkers);
+    return k > 0 ? (k > 8 ? 8 : k) : 2;
+}
+
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode)
 {
+    const int workers = host_workers_for(b, mode == LZ4HIP_MODE_HC);
+    int dev = 0;
+    if (workers > 1 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+        return run_host_batch_multi(b, true, 1ull << dev, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); }, 0, workers);
     return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); },
                           mode == LZ4HIP_MODE_HC ? kHcHostSliceBlocks : 0);
 }
 
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
 {
+    const int workers = host_workers_for(b, 0);
+    int dev = 0;
+    if (workers > 1 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+        return run_host_batch_multi(b, !known_output_size, 1ull << dev,
+                                    [known_output_size](const lz4hip_batch_t* db, hipStream_t s) { return launch_decode(db, known_output_size, s); }, 0, workers);
     return run_host_batch(b, !known_output_size,
                           [known_output_size](const lz4hip_batch_t* db, hipStream_t s) { return launch_decode(db, known_output_size, s); });
 }

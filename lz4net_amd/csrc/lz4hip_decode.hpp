@@ -144,8 +144,9 @@ LZ4HIP_DEVICE void wave_match_copy(uint8_t* dst, int pos, int off, int n)
     }
 }
 
+struct alignas(8) BurstRec { uint32_t x, y; };   // a burst's sequence: token lane | literals << 8 | offset << 16; first output byte
 constexpr int kWaveRingBytes = 4096;     // LDS mirror of a wavefront's most recent output (power of two)
-constexpr int kWaveBurstRecBytes = 1024; // ... followed by the burst's sequence records (64 x 16 bytes)
+constexpr int kWaveBurstRecBytes = 1024; // ... followed by the burst's sequence records (at most 64 x 8 bytes)
 constexpr int kWaveLdsBytes = kWaveRingBytes + kWaveBurstRecBytes;
 
 template <bool KNOWN>
@@ -186,21 +187,33 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
         else if (op <= o_burst && ip <= i_burst) {
             win.need(ip, 96);
             const int idx0 = ip - win.base, J0 = idx0 >> 2, ph = idx0 & 3;
-            // this lane's twelve bytes at ip + lane: three window dwords, fetched from both halves of the window in ONE round of
-            // cross-lane reads (a first version went through an intermediate register: two dependent rounds)
+            // this lane's seventeen bytes at ip + lane (token, <= 14 literals, offset; or token, <= 13 literals, offset, one length byte):
+            // five window dwords, fetched from both halves of the window in ONE round of cross-lane reads.  (Until round 6: twelve bytes,
+            // <= 6 literals and no length byte -- one sequence in eight of fuzzer-style data then left the burst for the general path,
+            // 1 900 cycles each and a third of a block's time: profiles/r06/decoder_wave_sections_s_memtime.txt.)
             const int bi = ph + lane, dj = J0 + (bi >> 2);
             const uint32_t a0 = wv::shuffle(win.w0, dj & 63), b0 = wv::shuffle(win.w1, dj & 63);
             const uint32_t a1 = wv::shuffle(win.w0, (dj + 1) & 63), b1 = wv::shuffle(win.w1, (dj + 1) & 63);
             const uint32_t a2 = wv::shuffle(win.w0, (dj + 2) & 63), b2 = wv::shuffle(win.w1, (dj + 2) & 63);
-            const uint32_t x0 = (dj & 64) ? b0 : a0, x1 = ((dj + 1) & 64) ? b1 : a1, x2 = ((dj + 2) & 64) ? b2 : a2;
+            const uint32_t a3 = wv::shuffle(win.w0, (dj + 3) & 63), b3 = wv::shuffle(win.w1, (dj + 3) & 63);
+            const uint32_t a4 = wv::shuffle(win.w0, (dj + 4) & 63), b4 = wv::shuffle(win.w1, (dj + 4) & 63);
+            const uint32_t x0 = (dj & 64) ? b0 : a0, x1 = ((dj + 1) & 64) ? b1 : a1, x2 = ((dj + 2) & 64) ? b2 : a2,
+                           x3 = ((dj + 3) & 64) ? b3 : a3, x4 = ((dj + 4) & 64) ? b4 : a4;
             const uint32_t sh = (uint32_t)bi & 3u;
-            const uint32_t v0 = wv::alignbyte(x1, x0, sh), v1 = wv::alignbyte(x2, x1, sh), v2 = x2 >> (8u * sh);
+            const uint32_t v0 = wv::alignbyte(x1, x0, sh), v1 = wv::alignbyte(x2, x1, sh), v2 = wv::alignbyte(x3, x2, sh),
+                           v3 = wv::alignbyte(x4, x3, sh), v4 = x4 >> (8u * sh);          // bytes 0 .. 15, and byte 16 in the low byte of v4
             const uint32_t tok = v0 & 255u, ll = tok >> 4, mlc = tok & 15u;
-            const uint64_t rest8 = ((((uint64_t)v1 << 32) | v0) >> 8) | ((uint64_t)(v2 & 255u) << 56);   // the eight bytes after the token
-            const uint32_t off = (uint32_t)(rest8 >> (8u * (ll > 6u ? 0u : ll))) & 0xFFFFu;
-            const bool simple = (ll <= 6u) & (mlc != 15u) & (off != 0u);
-            const uint32_t olen = ll + mlc + (uint32_t)kMinMatch;
-            const uint32_t packed = olen | ((3u + ll) << 8);          // output bytes | input bytes of the sequence
+            // offset (and the length byte behind it) at byte 1 + ll of that view
+            const uint32_t fo = 1u + ll, fq = fo >> 2;                // (ll == 15: fq == 4, not simple, the values below are not used)
+            const uint32_t flo = fq == 0u ? v0 : (fq == 1u ? v1 : (fq == 2u ? v2 : v3));
+            const uint32_t fhi = fq == 0u ? v1 : (fq == 1u ? v2 : (fq == 2u ? v3 : v4));
+            const uint32_t ot = wv::alignbyte(fhi, flo, fo & 3u);
+            const uint32_t off = ot & 0xFFFFu, ext = (ot >> 16) & 255u;
+            const bool longm = mlc == 15u;                            // match length 19 + one length byte (255 = more of them: general path)
+            const bool simple = (ll <= 14u) & (off != 0u) & (!longm | ((ext != 255u) & (ll <= 13u)));
+            const uint32_t olen_full = ll + mlc + (uint32_t)kMinMatch + (longm ? ext : 0u);
+            const uint32_t olen = olen_full > 255u ? 255u : olen_full;            // (anything above 64 ends the walk)
+            const uint32_t packed = olen | ((3u + ll + (longm ? 1u : 0u)) << 8);  // output bytes | input bytes of the sequence
             // the real sequence starts, from lane 0 on: a wave-uniform walk, one v_readlane per sequence
             const uint64_t simple_m = wv::ballot(simple);
             int s_tok = 0, tot = 0;
@@ -220,16 +233,17 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                 const bool is_tok = (tok_m >> lane) & 1ull;
                 const uint32_t mine = is_tok ? olen : 0u;
                 const uint32_t ost = wv::scan_add(mine) - mine;      // where this token's sequence starts in the burst's output
-                Aligned16* const rec = (Aligned16*)(ring + kWaveRingBytes);
-                if (is_tok) rec[wv::rank_below(tok_m)] = Aligned16{ { ll | (off << 8), (uint32_t)rest8, (uint32_t)(rest8 >> 32), ost } };
+                BurstRec* const rec = (BurstRec*)(ring + kWaveRingBytes);
+                if (is_tok) rec[wv::rank_below(tok_m)] = BurstRec{ (uint32_t)lane | (ll << 8) | (off << 16), ost };
                 wv::mem_sync();
                 const bool live = lane < tot;
                 const int k = wv::rank_below(bound_m) + (int)((bound_m >> lane) & 1ull) - 1;   // the sequence of output byte `lane`
-                const Aligned16 r = rec[live ? k : 0];
-                const int t_ll = (int)(r.w[0] & 255u), t_off = (int)(r.w[0] >> 8);
-                const int rel = lane - (int)r.w[3];
+                const BurstRec r = rec[live ? k : 0];
+                const int t_tl = (int)(r.x & 255u), t_ll = (int)((r.x >> 8) & 255u), t_off = (int)(r.x >> 16);
+                const int rel = lane - (int)r.y;
                 const bool is_lit = rel < t_ll;
-                const uint32_t litb = (uint32_t)((((uint64_t)r.w[2] << 32) | r.w[1]) >> (8 * (is_lit ? rel : 0))) & 255u;
+                // a literal comes straight out of the register window: byte 1 + rel behind its sequence's token
+                const uint32_t litb = win.gather(ip + t_tl + 1 + (is_lit ? rel : 0));
                 const int srel = lane - t_off;                       // a match byte's source, relative to the burst's first byte
                 const bool hist = live & !is_lit & (srel < 0);
                 const int habs = op + srel;

@@ -119,8 +119,13 @@ LZ4HIP_DEVICE int skip_sum(int a) { const int q = a >> 6, r = a & 63; return 32 
 // table entry.  Then the buckets get back their old entries, and of the lanes up to the winner the highest one of each
 // bucket writes its position -- the table ends up exactly as the serial loop leaves it.
 // In: ip = first probe position.  Out (true): ip = match position, ref = candidate.  False: ran out of input.
+// have_first / first_words: the caller has already loaded the words of the FIRST step (lane l: the dword at ip + first_probe_offset(l),
+// 0 where that would leave the input) -- they were requested before the search was known to be needed, so the search starts without a
+// round trip to memory.
+LZ4HIP_DEVICE int first_probe_offset(int lane) { return lane < 61 ? lane : 2 * lane - 61; }   // skip_sum(67 + lane) - skip_sum(67): 0 .. 60, 61, 63, 65
 template <bool GENERIC>
-LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit)
+LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit,
+                                   bool have_first = false, uint32_t first_words = 0)
 {
     typedef FastTable<GENERIC> T;
     typedef typename T::entry entry;
@@ -133,7 +138,8 @@ LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC
         const int p_next = p + (a >> 6);
         const bool valid = p_next <= mflimit;                        // (monotonic: the probing lanes are a prefix)
         uint32_t w = 0;
-        if (valid) w = load_u32(in + p);
+        if (have_first && attempts == 67) w = valid ? first_words : 0u;   // (wave-uniform condition; p + 4 <= n for every valid lane)
+        else if (valid) w = load_u32(in + p);
         const uint32_t h = T::hash(w);
         int r = 0;
         if (valid) r = (int)table[h];
@@ -308,7 +314,9 @@ tail:
 struct FastSeq { int op; bool ok; };
 // One sequence: token + literal length bytes + ll literals from in[anchor..] + offset + match length bytes; mlen = the whole match (>= 4).
 // The limit tests are those of lz4.c:663 / :728 in the reference's order (and the two of the first version that stand for its stray writes).
-LZ4HIP_DEVICE FastSeq emit_fast_sequence(const uint8_t* in, uint8_t* out, int cap, int op, int anchor, int ll, uint32_t off, int mlen)
+// have_lits / lits: lane j >= 1 already holds in[anchor + j - 1] (requested before the search), so the one-store form needs no load.
+LZ4HIP_DEVICE FastSeq emit_fast_sequence(const uint8_t* in, uint8_t* out, int cap, int op, int anchor, int ll, uint32_t off, int mlen,
+                                         bool have_lits = false, uint32_t lits = 0)
 {
     const int lane = wv::lane();
     const int extra = mlen - kMinMatch;
@@ -319,7 +327,7 @@ LZ4HIP_DEVICE FastSeq emit_fast_sequence(const uint8_t* in, uint8_t* out, int ca
         const uint32_t tok = ((uint32_t)ll << 4) | (uint32_t)extra;
         if (lane < ll + 3) {
             uint32_t v = tok;
-            if (lane >= 1 && lane <= ll) v = in[anchor + lane - 1];
+            if (lane >= 1 && lane <= ll) v = have_lits ? lits : (uint32_t)in[anchor + lane - 1];
             if (lane > ll) v = lane == ll + 1 ? (off & 255u) : (off >> 8);
             out[op + lane] = (uint8_t)v;
         }
@@ -360,12 +368,21 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
         // the register window: lane l holds in[wbase + 4 l .. + 4) (0 past the end); a qword at q comes out of it while 0 <= q - wbase <= 244
         uint32_t win = 0;
         int wbase = -(1 << 20);
+        // the words of the next search's first 64-probe step, requested by the test-next-position iteration before it knows whether it hits
+        bool have_first = false;
+        uint32_t first_words = 0;
+        const int first_off = first_probe_offset(lane);
         ip = 1;                                                       // lz4.c:631: position 0 is never probed
         for (;;) {
             // ---- find a match: lz4.c:642-654, 64 probes of the skip schedule per step ----
             int ref = 0;
             LZ4HIP_ENC_T0();
-            if (!wave_find_match<false>(in, table, ip, ref, mflimit)) break;
+            // (the literals of the sequence this search ends in start at `anchor`: lane j >= 1 fetches in[anchor + j - 1] now -- it is there
+            //  long before the sequence is emitted)
+            uint32_t pre_lits = 0;
+            if (lane >= 1 && anchor + lane - 1 < n) pre_lits = in[anchor + lane - 1];
+            if (!wave_find_match<false>(in, table, ip, ref, mflimit, have_first, first_words)) break;
+            have_first = false;
             LZ4HIP_ENC_T(0);
             // ---- catch up: lz4.c:657 (the first 256 bytes of the forward count are requested before it, see the first version) ----
             const uint32_t fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
@@ -378,7 +395,7 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
             // ---- literals, offset, match length: lz4.c:660-733 ----
             {
                 const int mlen = kMinMatch + caught_up + wave_common_length(in, ip + kMinMatch + caught_up, ref + kMinMatch + caught_up, matchlimit, fwd_round);
-                const FastSeq e = emit_fast_sequence(in, out, cap, op, anchor, ip - anchor, (uint32_t)(ip - ref) & 0xFFFFu, mlen);
+                const FastSeq e = emit_fast_sequence(in, out, cap, op, anchor, ip - anchor, (uint32_t)(ip - ref) & 0xFFFFu, mlen, true, pre_lits);
                 if (!e.ok) return 0;
                 op = e.op;
                 ip += mlen; anchor = ip;
@@ -395,6 +412,10 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
                 const bool wide = ip + 256 <= matchlimit;             // 256 bytes from ip may be read and counted (wave-uniform)
                 uint32_t a4 = 0;
                 if (wide) a4 = load_u32(in + ip + 4 * lane);          // the ip side of test + count, on its way while the table is looked up
+                // if this test misses, the search starts at ip + 1: its first step's words travel with the load above
+                first_words = 0;
+                if (ip + 1 + first_off + 4 <= n) first_words = load_u32(in + ip + 1 + first_off);
+                have_first = true;
                 // bytes ip-2 .. ip+5 (ip <= mflimit: inside the block) out of the window
                 const int q = ip - 2;
                 int rel = q - wbase;
