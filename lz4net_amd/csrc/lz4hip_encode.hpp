@@ -123,66 +123,84 @@ LZ4HIP_DEVICE int skip_sum(int a) { const int q = a >> 6, r = a & 63; return 32 
 // 0 where that would leave the input) -- they were requested before the search was known to be needed, so the search starts without a
 // round trip to memory.
 LZ4HIP_DEVICE int first_probe_offset(int lane) { return lane < 61 ? lane : 2 * lane - 61; }   // skip_sum(67 + lane) - skip_sum(67): 0 .. 60, 61, 63, 65
-template <bool GENERIC>
-LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit,
-                                   bool have_first = false, uint32_t first_words = 0)
+// One 64-probe step.  ALLV: every lane's probe is known to be inside the input (the caller tested the last lane's), so nothing of the step
+// runs under a lane mask -- a guarded load or table access is a saveexec / restore pair and a branch each, a dozen of them per step.
+// Returns 0: 64 probes without a match (ip = next probe position), 1: match (ip, ref), 2: ran out of input.
+template <bool GENERIC, bool ALLV>
+LZ4HIP_DEVICE int wave_find_step(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit, int attempts,
+                                 bool have_words, uint32_t words)
 {
     typedef FastTable<GENERIC> T;
     typedef typename T::entry entry;
     const int lane = wv::lane();
     const uint64_t below_me = (1ull << lane) - 1ull;
+    const int a = attempts + lane;
+    const int p = ip + skip_sum(a) - skip_sum(attempts);
+    const int p_next = p + (a >> 6);
+    const bool valid = ALLV || p_next <= mflimit;                    // (monotonic: the probing lanes are a prefix)
+    uint32_t w = 0;
+    if (have_words) w = valid ? words : 0u;                          // (wave-uniform condition; p + 4 <= n for every valid lane)
+    else if (valid) w = load_u32(in + p);
+    const uint32_t h = T::hash(w);
+    int r = 0;
+    if (valid) r = (int)table[h];
+    uint32_t rw = 0;                                                 // the candidate's bytes, for lanes alone in their bucket
+    if (valid) rw = load_u32(in + r);
+    wv::mem_sync();
+    if (valid) table[h] = (entry)lane;
+    wv::mem_sync();
+    uint64_t shared = wv::ballot(valid && (int)table[h] != lane);
+    wv::mem_sync();
+    uint64_t bucket = 0;                                             // the lanes of this lane's bucket (0: alone)
+    while (shared) {                                                 // rare: one round per shared bucket
+        const uint32_t hb = wv::readlane(h, wv::ctz64(shared));
+        const uint64_t g = wv::ballot(valid && h == hb);
+        if (valid && h == hb) bucket = g;
+        shared &= ~g;
+    }
+    const uint64_t lower = bucket & below_me;
+    const int prev = lower ? 63 - __builtin_clzll(lower) : lane;
+    const uint32_t pw = wv::shuffle(w, prev);
+    const int pp = (int)wv::shuffle((uint32_t)p, prev);
+    const int cref = lower ? pp : r;
+    const bool cand = valid && (!GENERIC || cref >= p - kMaxDistance) && (lower ? pw : rw) == w;   // lz4.c:427 / :654
+    const uint64_t stop = wv::ballot(cand || !valid);
+    const int m = stop ? wv::ctz64(stop) : 63;                       // the last lane of this step that probes (if valid)
+    // table: lanes after the winner restore their bucket, of the others the highest lane of each bucket writes
+    if (wv::any(bucket != 0)) {
+        if (valid) table[h] = (entry)r;                              // (lanes of one bucket hold the same old entry)
+        wv::mem_sync();
+        const uint64_t upto_m = m >= 63 ? ~0ull : ((2ull << m) - 1ull);
+        const uint64_t higher = bucket & ~below_me & ~(1ull << lane) & upto_m;
+        if (valid && lane <= m && higher == 0) table[h] = (entry)p;
+    } else if (valid) {
+        table[h] = (entry)(lane <= m ? p : r);
+    }
+    wv::mem_sync();
+    if (stop) {
+        if (!ALLV && !wv::readlane((uint32_t)valid, m)) return 2;
+        ip = (int)wv::readlane((uint32_t)p, m);
+        ref = (int)wv::readlane((uint32_t)cref, m);
+        return 1;
+    }
+    ip = (int)wv::readlane((uint32_t)p_next, 63);                    // 64 probes without a match
+    return 0;
+}
+
+template <bool GENERIC>
+LZ4HIP_DEVICE bool wave_find_match(const uint8_t* in, typename FastTable<GENERIC>::entry* table, int& ip, int& ref, int mflimit,
+                                   bool have_first = false, uint32_t first_words = 0)
+{
     int attempts = 67;
     for (;;) {
-        const int a = attempts + lane;
-        const int p = ip + skip_sum(a) - skip_sum(attempts);
-        const int p_next = p + (a >> 6);
-        const bool valid = p_next <= mflimit;                        // (monotonic: the probing lanes are a prefix)
-        uint32_t w = 0;
-        if (have_first && attempts == 67) w = valid ? first_words : 0u;   // (wave-uniform condition; p + 4 <= n for every valid lane)
-        else if (valid) w = load_u32(in + p);
-        const uint32_t h = T::hash(w);
-        int r = 0;
-        if (valid) r = (int)table[h];
-        uint32_t rw = 0;                                             // the candidate's bytes, for lanes alone in their bucket
-        if (valid) rw = load_u32(in + r);
-        wv::mem_sync();
-        if (valid) table[h] = (entry)lane;
-        wv::mem_sync();
-        uint64_t shared = wv::ballot(valid && (int)table[h] != lane);
-        wv::mem_sync();
-        uint64_t bucket = 0;                                         // the lanes of this lane's bucket (0: alone)
-        while (shared) {                                             // rare: one round per shared bucket
-            const uint32_t hb = wv::readlane(h, wv::ctz64(shared));
-            const uint64_t g = wv::ballot(valid && h == hb);
-            if (valid && h == hb) bucket = g;
-            shared &= ~g;
-        }
-        const uint64_t lower = bucket & below_me;
-        const int prev = lower ? 63 - __builtin_clzll(lower) : lane;
-        const uint32_t pw = wv::shuffle(w, prev);
-        const int pp = (int)wv::shuffle((uint32_t)p, prev);
-        const int cref = lower ? pp : r;
-        const bool cand = valid && (!GENERIC || cref >= p - kMaxDistance) && (lower ? pw : rw) == w;   // lz4.c:427 / :654
-        const uint64_t stop = wv::ballot(cand || !valid);
-        const int m = stop ? wv::ctz64(stop) : 63;                   // the last lane of this step that probes (if valid)
-        // table: lanes after the winner restore their bucket, of the others the highest lane of each bucket writes
-        if (wv::any(bucket != 0)) {
-            if (valid) table[h] = (entry)r;                          // (lanes of one bucket hold the same old entry)
-            wv::mem_sync();
-            const uint64_t upto_m = m >= 63 ? ~0ull : ((2ull << m) - 1ull);
-            const uint64_t higher = bucket & ~below_me & ~(1ull << lane) & upto_m;
-            if (valid && lane <= m && higher == 0) table[h] = (entry)p;
-        } else if (valid) {
-            table[h] = (entry)(lane <= m ? p : r);
-        }
-        wv::mem_sync();
-        if (stop) {
-            if (!wv::readlane((uint32_t)valid, m)) return false;
-            ip = (int)wv::readlane((uint32_t)p, m);
-            ref = (int)wv::readlane((uint32_t)cref, m);
-            return true;
-        }
-        ip = (int)wv::readlane((uint32_t)p_next, 63);                // 64 probes without a match
+        // the LAST lane's probe inside the input (wave-uniform arithmetic): then every lane's is
+        const int a63 = attempts + 63;
+        const bool all_valid = ip + skip_sum(a63) - skip_sum(attempts) + (a63 >> 6) <= mflimit;
+        const bool hw = have_first && attempts == 67;
+        const int st = all_valid ? wave_find_step<GENERIC, true>(in, table, ip, ref, mflimit, attempts, hw, first_words)
+                                 : wave_find_step<GENERIC, false>(in, table, ip, ref, mflimit, attempts, hw, first_words);
+        if (st == 1) return true;
+        if (st == 2) return false;
         attempts += 64;
         LZ4HIP_ENC_COUNT(4, 1);
     }
@@ -384,17 +402,33 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
             if (!wave_find_match<false>(in, table, ip, ref, mflimit, have_first, first_words)) break;
             have_first = false;
             LZ4HIP_ENC_T(0);
-            // ---- catch up: lz4.c:657 (the first 256 bytes of the forward count are requested before it, see the first version) ----
-            const uint32_t fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
-            int caught_up = 0;
+            // ---- catch up (lz4.c:657), literals, offset, match length (lz4.c:660-733) ----
+            // Away from the end of the block all four loads -- 64 bytes before both positions for the catch-up, 256 bytes behind both for the
+            // count -- are issued together, unconditionally, and waited for ONCE (written as a guarded round each, the compiler waits for the
+            // count's loads before it even issues the catch-up's: two round trips).  The catch-up bytes are clamped to the block's start and
+            // only compared below `bound`; the count is from the probe position (what a catch-up adds in front lies inside what is known to be equal).
             {
+                int mlen;
                 const int room = ip - anchor, bound = room < ref ? room : ref;
-                const int back = bound > 0 ? wave_catch_up(in, ip, ref, bound) : 0;
-                ip -= back; ref -= back; caught_up = back;
-            }
-            // ---- literals, offset, match length: lz4.c:660-733 ----
-            {
-                const int mlen = kMinMatch + caught_up + wave_common_length(in, ip + kMinMatch + caught_up, ref + kMinMatch + caught_up, matchlimit, fwd_round);
+                if (ip + kMinMatch + 256 <= matchlimit) {
+                    const int ia = ip - 1 - lane, ib = ref - 1 - lane;
+                    const uint32_t ca = in[ia > 0 ? ia : 0], cb = in[ib > 0 ? ib : 0];
+                    const uint32_t diff = load_u32(in + ip + kMinMatch + 4 * lane) ^ load_u32(in + ref + kMinMatch + 4 * lane);
+                    const uint64_t differs = wv::ballot(lane >= bound || ca != cb);
+                    int back = differs ? wv::ctz64(differs) : 64;
+                    if (back == 64 && bound > 64) back = 64 + wave_catch_up(in, ip - 64, ref - 64, bound - 64);
+                    const uint64_t stop = wv::ballot(diff != 0);
+                    int fwd;
+                    if (stop) { const int first = wv::ctz64(stop); fwd = first * 4 + (__builtin_ctz(wv::readlane(diff, first)) >> 3); }
+                    else fwd = 256 + wave_common_length(in, ip + kMinMatch + 256, ref + kMinMatch + 256, matchlimit);
+                    ip -= back; ref -= back;
+                    mlen = kMinMatch + back + fwd;
+                } else {
+                    const uint32_t fwd_round = common_length_round(in, ip + kMinMatch, ref + kMinMatch, matchlimit, 0);
+                    const int back = bound > 0 ? wave_catch_up(in, ip, ref, bound) : 0;
+                    ip -= back; ref -= back;
+                    mlen = kMinMatch + back + wave_common_length(in, ip + kMinMatch + back, ref + kMinMatch + back, matchlimit, fwd_round);
+                }
                 const FastSeq e = emit_fast_sequence(in, out, cap, op, anchor, ip - anchor, (uint32_t)(ip - ref) & 0xFFFFu, mlen, true, pre_lits);
                 if (!e.ok) return 0;
                 op = e.op;
@@ -409,21 +443,27 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
                     checked_at = ip;
                 }
                 if (ip > mflimit) { anchor = ip; goto tail; }        // lz4.c:736
-                const bool wide = ip + 256 <= matchlimit;             // 256 bytes from ip may be read and counted (wave-uniform)
-                uint32_t a4 = 0;
-                if (wide) a4 = load_u32(in + ip + 4 * lane);          // the ip side of test + count, on its way while the table is looked up
-                // if this test misses, the search starts at ip + 1: its first step's words travel with the load above
-                first_words = 0;
-                if (ip + 1 + first_off + 4 <= n) first_words = load_u32(in + ip + 1 + first_off);
-                have_first = true;
-                // bytes ip-2 .. ip+5 (ip <= mflimit: inside the block) out of the window
+                // bytes ip-2 .. ip+5 (ip <= mflimit: inside the block) out of the window; re-based here -- BEFORE this iteration's loads are
+                // requested, and waited for inside the branch: a wait behind the join would make every iteration wait for those loads too
                 const int q = ip - 2;
                 int rel = q - wbase;
                 if ((unsigned)rel > 244u) {
                     wbase = q; rel = 0;
                     const int pos = q + 4 * lane;
                     win = pos + 4 <= n ? load_u32(in + pos) : 0u;
+                    wv::wait_vector_memory();
+                    LZ4HIP_KEEP(win);
                 }
+                const bool wide = ip + 256 <= matchlimit;             // 256 bytes from ip may be read and counted (wave-uniform)
+                // Both loads are issued in EVERY iteration, from addresses clamped to the block (n >= 13 here): a load under a condition
+                // needs its register zeroed first, and that write has to wait for whatever load into the same register is still in
+                // flight -- on gfx9 together with every store issued before it.  What a clamped lane reads is never used (a4 only when
+                // `wide`, first_words only by lanes whose probe position is valid).
+                const int last4 = n - 4;
+                const int pa = ip + 4 * lane, pf = ip + 1 + first_off;
+                const uint32_t a4 = load_u32(in + (pa < last4 ? pa : last4));          // the ip side of test + count, on its way while the table is looked up
+                first_words = load_u32(in + (pf < last4 ? pf : last4));               // if this test misses, the search starts at ip + 1: its first step's words
+                have_first = true;
                 const int k = rel >> 2;
                 const uint32_t sh = ((uint32_t)rel & 3u) * 8u;
                 const uint32_t d0 = wv::readlane(win, k), d1 = wv::readlane(win, k + 1), d2 = wv::readlane(win, k + 2);
@@ -431,10 +471,12 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
                 const uint32_t w_p2 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);     // bytes ip+2 .. ip+5
                 const uint32_t cur_word = (w_m2 >> 16) | (w_p2 << 16);                   // bytes ip .. ip+3
                 const uint32_t h2 = T::hash(w_m2), h = T::hash(cur_word);
+                LZ4HIP_ENC_T(4);
                 table[h2] = (uint16_t)(ip - 2);                       // (every lane stores the same value: no lane mask to set up)
                 wv::mem_sync();
                 const int ref2 = (int)wv::uniform((uint32_t)table[h]);
                 table[h] = (uint16_t)ip;
+                LZ4HIP_ENC_T(5);
                 int mlen;
                 if (wide) {
                     const uint32_t diff = a4 ^ load_u32(in + ref2 + 4 * lane);
@@ -450,6 +492,7 @@ LZ4HIP_DEVICE int encode_fast_block64k(const uint8_t* in, int n, uint8_t* out, i
                     if (input_word(in, ref2) != cur_word) { LZ4HIP_ENC_T(3); break; }
                     mlen = kMinMatch + wave_common_length(in, ip + kMinMatch, ref2 + kMinMatch, matchlimit);
                 }
+                LZ4HIP_ENC_T(6);
                 const FastSeq e = emit_fast_sequence(in, out, cap, op, ip, 0, (uint32_t)(ip - ref2) & 0xFFFFu, mlen);   // zero-literal sequence (lz4.c:751)
                 if (!e.ok) return 0;
                 op = e.op;

@@ -8,13 +8,13 @@
 #include <cstdint>
 #include <vector>
 #include "lz4hip_wave.hpp"
-__device__ unsigned long long g_cyc[8], g_cnt[8];
+__device__ unsigned long long g_cyc[8], g_cnt[8];   // (slots 4, 5 are timed in every test-next-position iteration, 6 / 2 only in those that hit, 3 in those that miss)
 // (accumulated in registers, written out once per block: an atomic per section would be most of what is measured)
-#define LZ4HIP_ENC_DECL() unsigned long long t_mark = 0, t_a0 = 0, t_a1 = 0, t_a2 = 0, t_a3 = 0; unsigned t_c0 = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_c4 = 0
+#define LZ4HIP_ENC_DECL() unsigned long long t_mark = 0, t_a0 = 0, t_a1 = 0, t_a2 = 0, t_a3 = 0, t_a4 = 0, t_a5 = 0, t_a6 = 0; unsigned t_c0 = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_c4 = 0, t_c5 = 0, t_c6 = 0
 #define LZ4HIP_ENC_T0() do { t_mark = __builtin_readcyclecounter(); } while (0)
 #define LZ4HIP_ENC_T(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_a##slot += now_ - t_mark; t_c##slot++; t_mark = now_; } while (0)
 #define LZ4HIP_ENC_COUNT(slot, n) ((void)0)
-#define LZ4HIP_ENC_FLUSH() do { if (threadIdx.x == 0) { atomicAdd(&g_cyc[0], t_a0); atomicAdd(&g_cyc[1], t_a1); atomicAdd(&g_cyc[2], t_a2); atomicAdd(&g_cyc[3], t_a3); \
+#define LZ4HIP_ENC_FLUSH() do { if (threadIdx.x == 0) { atomicAdd(&g_cyc[0], t_a0); atomicAdd(&g_cyc[1], t_a1); atomicAdd(&g_cyc[2], t_a2); atomicAdd(&g_cyc[3], t_a3); atomicAdd(&g_cyc[4], t_a4); atomicAdd(&g_cyc[5], t_a5); atomicAdd(&g_cyc[6], t_a6); atomicAdd(&g_cnt[4], (unsigned long long)t_c4); atomicAdd(&g_cnt[5], (unsigned long long)t_c5); atomicAdd(&g_cnt[6], (unsigned long long)t_c6); \
     atomicAdd(&g_cnt[0], (unsigned long long)t_c0); atomicAdd(&g_cnt[1], (unsigned long long)t_c1); atomicAdd(&g_cnt[2], (unsigned long long)t_c2); atomicAdd(&g_cnt[3], (unsigned long long)t_c3); } } while (0)
 #include "lz4hip_common.hpp"
 #include "lz4hip_encode.hpp"
@@ -51,8 +51,9 @@ int main(int argc, char** argv)
         long long csum = 0; for (int v : r) csum += v;
         if (rep == 0) continue;
         printf("dist %d, %d blocks (one wavefront each), kernel %.3f ms, mean compressed %.0f B; cycle counter ticks per block %.0f\n", dist, n, ms, (double)csum / n, (double)tot / n);
-        const char* name[4] = { "match search (wave_find_match)", "catch-up + count + emit after a search", "test-next-position iteration that hits", "test-next-position iteration that misses" };
-        for (int k = 0; k < 4; k++)
+        const char* name[7] = { "match search (wave_find_match)", "catch-up + count + emit after a search", "test-next-position that hits: emit (after the count)", "test-next-position that misses: after the table",
+                                "test-next-position: checks, loads issued, window, hashes", "test-next-position: table put / get / put", "test-next-position that hits: candidate load, test + count" };
+        for (int k = 0; k < 7; k++)
             printf("  %-44s %9.0f per block x %7.0f ticks = %5.1f %% of the block's ticks\n", name[k], (double)cnt[k] / n, cnt[k] ? (double)cyc[k] / cnt[k] : 0.0, 100.0 * cyc[k] / (double)tot);
     }
     return 0;

@@ -15,7 +15,7 @@ rm -rf $T
 ls -la build_variants
 #   enc_wave_a.so    the working tree with lz4hip_encode.hpp as of commit 84019f8 (second version of the 64k encoder, no prefetches)
 #   enc_wave_b.so    the working tree (the next search's first-step words and the next sequence's literals requested ahead)
-cp build_variants/wave_dec_new.so build_variants/enc_wave_b.so
+/opt/rocm/bin/hipcc $F -Ilz4net_amd/csrc lz4net_amd/csrc/lz4hip_api.hip -o build_variants/enc_wave_b.so
 T=$(mktemp -d); mkdir -p $T/lz4net_amd $T/tools; cp -r lz4net_amd/csrc $T/lz4net_amd/; cp -r include $T/; cp -r tools/ab $T/tools/
 git show 84019f8:lz4net_amd/csrc/lz4hip_encode.hpp > $T/lz4net_amd/csrc/lz4hip_encode.hpp
 /opt/rocm/bin/hipcc $F -I$T/lz4net_amd/csrc $T/lz4net_amd/csrc/lz4hip_api.hip -o build_variants/enc_wave_a.so
