@@ -532,6 +532,30 @@ def main():
             sweep["ok"] = last_m > 0 and batch.count_mismatches(raw_s[:last_m], back_s[:last_m], batch.BLOCK) == 0
             extras["batch_size_sweep_" + DIST_NAMES[args.dist].split("(")[0]] = sweep
             del raw_s, comp_s, back_s
+            # ---- the wavefront-mapped fast encoder on its own (what every batch below 32 768 blocks and every host-pointer slice runs; second
+            #      version since round 6): 65 536 blocks of both sequence-dense distributions, forced mapping, EVERY block against the CPU reference ----
+            wave_enc = {}
+            for d in (2, 3):
+                torch.cuda.empty_cache()
+                m = min(65536, n)
+                raw_w = batch.synth(d, seed, 0, m)
+                comp_w = torch.empty((m, batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+                with _lib.tuning(encoder="wave"):
+                    clen_w = batch.encode(raw_w, batch.BLOCK, comp_w, batch.BOUND)
+                    torch.cuda.synchronize()
+                    hold = {}
+                    t_w = min(event_ms(lambda: hold.__setitem__("c", batch.encode(raw_w, batch.BLOCK, comp_w, batch.BOUND)), torch) for _ in range(2))
+                    clen_w = hold["c"]
+                chk = None
+                if not args.no_cpu and args.verify_budget > 0:
+                    try:
+                        chk = full_corpus_encoder_check(torch, batch, comp_w, clen_w, False, d, seed, 0, 1, args.verify_budget)
+                    except Exception as e:
+                        chk = {"error": repr(e)}
+                wave_enc[DIST_NAMES[d]] = {"encode_fast_GBps": round(m * batch.BLOCK / (t_w / 1e3) / 1e9, 2), "blocks": m, "bit_exact_vs_cpu_reference": chk}
+                del raw_w, comp_w
+            extras["wavefront_encoder_forced"] = wave_enc
+            torch.cuda.empty_cache()
             # ---- the HBM roof measured on this box (quote the 8 TB/s spec AND what a copy reaches) ----
             torch.cuda.empty_cache()
             words = (4 << 30) // 8
