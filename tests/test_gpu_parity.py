@@ -74,6 +74,46 @@ def test_fast_encode_bit_exact(gpu, oracle, encoder):
         assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
 
 
+def test_fast_encode_wave_second_version_paths(gpu, oracle):
+    """The second version of the wavefront-mapped 64k encoder (lz4hip_encode.hpp, encode_fast_block64k; round 6) on the GPU: its register
+    window (re-based every ~244 bytes and after long matches), the combined candidate test + 256-byte count, its continuation past 256
+    equal bytes and the byte-wise form near the end of a block, the merged catch-up + count loads, the one-store sequence emit next to the
+    general one -- sizes around every threshold, dense / sparse / periodic / long-run data, exact and too-small output limits.  The twin of
+    tests/test_simt_emulation.py::test_encode_fast64k_window_wide_count_and_single_store_paths, through the C ABI with the mapping forced."""
+    rng = np.random.default_rng(606)
+    blocks = []
+    for n in list(range(13, 40)) + [255, 256, 257, 260, 261, 262, 263, 268, 269, 270, 300, 511, 512, 513, 517, 518, 519, 777, 1200, 5000, 33333, 65536, 65546]:
+        for dist in (2, 3):
+            blocks.append(oracle.gen(dist, 600 + n, n, 1, n)[0][:n])
+    for n in (300, 1000, 4000, 20000, 65536):
+        blocks.append(rng.integers(0, 2, n, dtype=np.uint8))
+        blocks.append(np.tile(rng.integers(0, 256, 7, dtype=np.uint8), n // 7 + 1)[:n])
+        a = np.tile(rng.integers(0, 256, 300, dtype=np.uint8), n // 300 + 1)[:n].copy()
+        a[rng.integers(0, n, max(n // 900, 1))] ^= 0x55
+        blocks.append(a)
+        b = rng.integers(0, 256, n, dtype=np.uint8)
+        for _ in range(n // 200):
+            src, ln, dstp = int(rng.integers(0, n - 40)), int(rng.integers(4, 40)), int(rng.integers(40, n - 40))
+            b[dstp:dstp + ln] = b[src:src + ln]
+        blocks.append(b)
+    want = [oracle.compress(a) for a in blocks]
+    with ForcedMapping("LZ4HIP_ENCODER", "wave"):
+        res, dst = gpu.encode(blocks)
+        for i, (a, w) in enumerate(zip(blocks, want)):
+            assert res[i] == len(w), (i, a.size, res[i], len(w))
+            assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
+            assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
+        for delta in (0, -1, -3, -9):
+            caps = [max(len(w) + delta, 0) for w in want]
+            res, dst = gpu.encode(blocks, caps=caps)
+            for i, a in enumerate(blocks):
+                r = oracle.compress_raw(a, caps[i])[0]
+                assert res[i] == r, (i, a.size, delta, res[i], r)
+                assert (dst[i, caps[i]:] == 0xA5).all(), (i, delta, "wrote past the capacity")
+                if r > 0:
+                    assert np.array_equal(dst[i, :r], want[i]), (i, delta)
+
+
 @pytest.fixture(params=["wave", "lane"])
 def hc_mapping(request):
     yield from _forced_fixture("LZ4HIP_HC", request.param)
