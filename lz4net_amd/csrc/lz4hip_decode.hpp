@@ -259,7 +259,11 @@ LZ4HIP_DEVICE int decode_block(const uint8_t* src, int src_len, uint8_t* dst, in
                         const uint32_t sv = wv::shuffle(val, srel & 63), sr = wv::shuffle(res ? 1u : 0u, srel & 63);
                         if (!res && sr != 0u) { val = sv; res = true; }
                     }
+#ifdef LZ4HIP_DEC_EXPERIMENT_NO_BURST_STORE                        /* (tools/dec_wave_sections.hip only: what do the burst's global store and the wait it causes cost?  wrong output) */
+                    if (live) { ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)val; }
+#else
                     if (live) { dst[op + lane] = (uint8_t)val; ring[(op + lane) & (kWaveRingBytes - 1)] = (uint8_t)val; }
+#endif
                     wv::mem_sync();
                     LZ4HIP_STAT(20, lane == 0); LZ4HIP_STAT_ADD(21, lane == 0 ? wv::popc64(tok_m) : 0); LZ4HIP_STAT_ADD(22, lane == 0 ? rounds : 0); (void)rounds;
                     LZ4HIP_DEC_ADD(4, wv::popc64(tok_m)); LZ4HIP_DEC_ADD(5, rounds);
