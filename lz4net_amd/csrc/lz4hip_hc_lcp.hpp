@@ -30,6 +30,9 @@
 #ifndef LZ4HIP_STAT
 #define LZ4HIP_STAT(slot, cond) ((void)0)   /* the emulator build counts lane-steps per state (tools/emu_hc_stats.py) */
 #endif
+#ifndef LZ4HIP_STAT_ADD
+#define LZ4HIP_STAT_ADD(slot, n) ((void)0)
+#endif
 
 namespace lz4hip {
 
@@ -208,6 +211,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
     int s_link = 0, s_lcp = 0;     // entry of s_ref (kept across the backward extension)
     uint32_t s_y = 0, s_ry = 0;    // ... its predecessor's byte behind the shared bytes; the same byte for the entries of a repeat fill
     int attempts = 0;
+    int stat_hops = 0;             // (emulator statistics only: candidates evaluated by the search in progress; dead code in product builds)
     uint32_t s_probe = 0;
     int s_probe_ok = 0;            // s_probe is in[start_limit + longest] for the current s_len (wider)
     int s_repl = 0, s_delta = 0;
@@ -236,6 +240,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
     auto request = [&](int pos, int start_limit, int longest, int match0, int start0_) {
         s_ip = pos; s_limit = start_limit; s_back = pos - start_limit; s_len = longest; s_match = match0; s_start = start0_;
         attempts = kHcAttempts; s_repl = 0; s_delta = 0; s_probe_ok = 0;
+        stat_hops = 0;
         st = kLsHead;
     };
 
@@ -333,6 +338,7 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
             }
         }
         if (hop_now) {
+            stat_hops++;
             s_link = (int)(v_e & 0xFFFFu); s_lcp = (int)((v_e >> 16) & 255u); s_y = v_e >> 24;
             if (phase == 0) {
                 if (s_first && s_ref >= s_ip - 4) {                  // lz4hc.c:411-421: not one of the attempts
@@ -389,7 +395,12 @@ __global__ void __launch_bounds__(64) encode_hc_lcp_kernel(Batch b, long long fi
         // the next candidate of the walk: c' = c - chain[c], F(c') from F(c) and lcp[c]; ends the search when the walk is over
         if (adv) {
             const int c2 = s_ref - s_link;
-            if (!(c2 >= s_ip - kMaxDistance && attempts > 0 && c2 >= 0)) st = (s_repl && phase == 0) ? (int)kLsRepl : (int)kLsCtrl;
+            if (!(c2 >= s_ip - kMaxDistance && attempts > 0 && c2 >= 0)) {
+                st = (s_repl && phase == 0) ? (int)kLsRepl : (int)kLsCtrl;
+                // (what a bucket-contiguous table would need for this search: its own entry + the candidates' entries, four per 16-byte read)
+                LZ4HIP_STAT_ADD(12, 1); LZ4HIP_STAT_ADD(13, stat_hops); LZ4HIP_STAT_ADD(14, (stat_hops + 1 + 3) / 4); LZ4HIP_STAT_ADD(15, (stat_hops + 1 + 7) / 8);
+                LZ4HIP_STAT(16, stat_hops <= 1); LZ4HIP_STAT(17, stat_hops >= 2 && stat_hops <= 3); LZ4HIP_STAT(18, stat_hops >= 4 && stat_hops <= 7); LZ4HIP_STAT(19, stat_hops >= 8 && stat_hops <= 31); LZ4HIP_STAT(20, stat_hops >= 32);
+            }
             else {
                 const int l = s_lcp;
                 s_ref = c2; s_first = 0;

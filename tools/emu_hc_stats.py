@@ -13,7 +13,9 @@ from oracle.oracle import Oracle
 
 NAMES = ["lane-steps (lane not finished)", "  head: entry of the search position", "  hop: candidate evaluated, its entry read", "  compare: 16 bytes of both sides", "  backward extension",
          "  repeat fill", "  waiting for the batched control flow", "walk advances to the next candidate", "  equal case (or both >= 255)", "    below the cap", "    search position's byte in the register window",
-         "    decided without a compare"]
+         "    decided without a compare",
+         "searches (walks that ended)", "  candidates evaluated by them", "  16-byte reads a bucket-contiguous table would need (own entry + candidates, 4 per read)", "  32-byte reads (8 per read)",
+         "  searches with <= 1 candidate", "  2-3", "  4-7", "  8-31", "  >= 32"]
 dist = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 o = Oracle()
