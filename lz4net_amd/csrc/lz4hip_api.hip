@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobHostWorkers, kKnobDecoderWrappedStores, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobHostWorkers, kKnobDecoderWg4, kKnobDecoderWrappedStores, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -68,6 +68,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
     { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2; 1 = the calling thread's pipeline alone, rounds 2-5)
+    { "decoder_wg4", "LZ4HIP_DECODER_WG4", false },                   // lane decoder, batches of at most one residency round: 0 default = workgroups of FOUR wavefronts (one per SIMD of a CU) while the batch has more than one and at most eight wavefronts per CU; 1 = always workgroups of one wavefront (rounds 1-5); 2 = the four-wavefront form from four wavefronts on (tests)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
 std::atomic<int> g_knob[kKnobCount];
@@ -793,8 +794,21 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 }
                 unsigned pg = (unsigned)(capacity < (int64_t)grid ? capacity : (int64_t)grid);
                 if (knob(kKnobDecoderGroups) > 0 && (unsigned)knob(kKnobDecoderGroups) < pg) pg = (unsigned)knob(kKnobDecoderGroups);
+                // one residency round at most, and few wavefronts per CU: workgroups of four wavefronts, so that the SIMDs of a CU share them evenly
+                // whatever ran before (decode_lane4_wg4_kernel)
+                // (from more than one wavefront per CU on: with at most one, single-wavefront workgroups spread evenly by themselves and keep the
+                //  dual ring stores, 8.19 vs 8.59 ms at 16 384 D2 blocks; knob decoder_wg4 = 2 takes the four-wavefront form from four wavefronts on: tests)
+                const int wg4_knob = knob(kKnobDecoderWg4);
+                const bool wg4 = mode == 0 && wg4_knob != 1 && (int64_t)grid >= 4 && (int64_t)grid > (wg4_knob == 2 ? 0 : (int64_t)cus) && (int64_t)grid <= (int64_t)cus * 8;
                 auto both_forms = [&](auto pol_tag) -> int {
                     constexpr int POLX = decltype(pol_tag)::value;
+                    if (wg4) {
+                        const unsigned g4 = (grid + 3u) / 4u;
+                        if (known) hipLaunchKernelGGL((decode_lane4_wg4_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(g4), dim3(256), 0, stream, d, lane_filter);
+                        else       hipLaunchKernelGGL((decode_lane4_wg4_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(g4), dim3(256), 0, stream, d, lane_filter);
+                        HIP_TRY(hipGetLastError());
+                        return 0;
+                    }
                     if (mode != 1) {
                         if (known) hipLaunchKernelGGL((decode_lane4_kernel<true, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
                         else       hipLaunchKernelGGL((decode_lane4_kernel<false, R_, P_, FU_, FS_, FE_, IE_, POLX>), dim3(grid), dim3(64), 0, stream, d, lane_filter, gate, mode == 2 ? 1 : 0, threshold);
@@ -815,6 +829,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
             LZ4HIP_LANE4_CASE(128); LZ4HIP_LANE4_CASE(2128); LZ4HIP_LANE4_CASE(6128); LZ4HIP_LANE4_CASE(3192); LZ4HIP_LANE4_CASE(192); LZ4HIP_LANE4_CASE(1192); LZ4HIP_LANE4_CASE(2192);
             LZ4HIP_LANE4_CASE(5192); LZ4HIP_LANE4_CASE(7192); LZ4HIP_LANE4_CASE(11192); LZ4HIP_LANE4_CASE(25192); LZ4HIP_LANE4_CASE(11256); LZ4HIP_LANE4_CASE(1256); LZ4HIP_LANE4_CASE(3256); LZ4HIP_LANE4_CASE(7256); LZ4HIP_LANE4_CASE(5256);
             LZ4HIP_LANE4_CASE(27192); LZ4HIP_LANE4_CASE(43192); LZ4HIP_LANE4_CASE(35192); LZ4HIP_LANE4_CASE(58128); LZ4HIP_LANE4_CASE(59256); LZ4HIP_LANE4_CASE(59224); LZ4HIP_LANE4_CASE(59208);
+            LZ4HIP_LANE4_CASE(59384); LZ4HIP_LANE4_CASE(59512); LZ4HIP_LANE4_CASE(59768); LZ4HIP_LANE4_CASE(59960);   /* round 6: large rings for batches that leave the LDS idle anyway (tools/r06/call12.sh) */
 #endif
             default: return fail(LZ4HIP_E_ARGUMENT, "decoder_ring: this library has no generation-4 lane decoder with that configuration");
             }

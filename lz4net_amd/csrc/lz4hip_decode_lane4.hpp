@@ -667,6 +667,32 @@ __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter, c
     if (active) b.result[blk] = r;
 }
 
+// FOUR wavefronts per workgroup: for batches that cannot give every SIMD a wavefront of its own anyway.  A wavefront alone on its SIMD needs
+// 8.4 ms for its 64 D2 blocks, two on one SIMD 10.5 each -- and where the hardware puts 1 024 single-wavefront workgroups depends on what ran
+// before them (a 65 536-block decode: 8.5 ms back to back, 10.5 ms behind the wavefront-mapped launch of the same call:
+// profiles/r06/decoder_mid_batches_placement.txt).  The four wavefronts of ONE workgroup go to the four SIMDs of one CU, and as many workgroups
+// as there are CUs spread one per CU.  The rings of the four wavefronts share one allocation, so the ring rows are WRAPPED here (POL bit 5 is
+// forced: a store at `row - ring size` would land in the neighbour's ring instead of being dropped).
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
+__global__ void __launch_bounds__(256) decode_lane4_wg4_kernel(Batch b, int filter)
+{
+    LZ4HIP_STATIC_LDS(lds_all, 4u * lane4_lds_bytes(R));
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = wv::wave_in_block();
+    const int64_t blk = ((int64_t)blockIdx.x * 4 + w) * 64 + lane;
+    bool active = blk < b.n_blocks;
+    int src_len = 0, out_size = 0;
+    if (active) {
+        src_len = batch_src_len(b, blk); out_size = batch_dst_cap(b, blk);
+        active = block_selected(filter, src_len, out_size);
+    }
+    if (!wv::any(active)) return;
+    const uint8_t* src = active ? batch_src(b, blk) : nullptr;
+    uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
+    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL | 32>(lds_all + (size_t)w * lane4_lds_bytes(R), lane, active, src, src_len, dst, out_size);
+    if (active) b.result[blk] = r;
+}
+
 // (what a lane of the persistent kernel does between two blocks)
 struct PullNext {
     static constexpr bool kPersistent = true;

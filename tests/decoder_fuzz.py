@@ -1,7 +1,8 @@
-"""Differential fuzz of the three decoder forms on the GPU (shared by tests/test_gpu_parity.py::test_decoder_fuzz_slice and
+"""Differential fuzz of the decoder forms on the GPU (shared by tests/test_gpu_parity.py::test_decoder_fuzz_slice and
 tools/fuzz_gpu_decoders.py): arbitrary LZ4 streams from tests/stream_fuzz.py -- well formed, truncated, extended, corrupted, with
 offset 0; offsets around every ring / window / burst threshold -- through the host-pointer C ABI with the wavefront mapping (bursts
-included), the lane mapping (one block per lane) and the persistent lane grid with ONE wavefront (every lane restarts many times);
+included), the lane mapping (one block per lane: workgroups of one wavefront, and -- round 6 -- of four wavefronts with wrapped ring rows) and the
+persistent lane grid with ONE wavefront (every lane restarts many times);
 known and unknown output size; results and bytes against the CPU oracle, canaries behind every row."""
 import time
 
@@ -10,7 +11,8 @@ import numpy as np
 import gpu_helpers as gpu
 import stream_fuzz
 
-FORMS = (("wave", dict(decoder="wave")), ("lane", dict(decoder="lane", decoder_persist=2)),
+FORMS = (("wave", dict(decoder="wave")), ("lane", dict(decoder="lane", decoder_persist=2, decoder_wg4=1)),
+         ("lane, four wavefronts per workgroup", dict(decoder="lane", decoder_persist=2, decoder_wg4=2)),
          ("persistent x1", dict(decoder="lane", decoder_persist=1, decoder_groups=1)))
 
 

@@ -454,7 +454,7 @@ def test_lds_out_of_range_stores_are_dropped(gpu, tmp_path):
 
 def test_decoder_fuzz_slice(gpu, oracle):
     """A 30-second slice of tools/fuzz_gpu_decoders.py in every -m gpu run (tests/decoder_fuzz.py): arbitrary streams x known / unknown
-    output size x the three decoder forms -- wavefront mapping with bursts, lane mapping, the persistent lane grid with ONE wavefront
+    output size x the four decoder forms -- wavefront mapping with bursts, lane mapping in workgroups of one and of four wavefronts, the persistent lane grid with ONE wavefront
     (every lane restarts with its predecessor's loads still in flight) -- against the CPU oracle: results, bytes, canaries.
     ALWAYS the same three seeds (1000..1002 with 240 streams each: a failure here reproduces on any box with
     `decoder_fuzz.run_seed(oracle, seed, 240)`), then, as an extra while the 30 seconds last, seeds that move with the day so that
@@ -466,7 +466,7 @@ def test_decoder_fuzz_slice(gpu, oracle):
     total, bad, done = decoder_fuzz.run(oracle, 1000, 3, per, seconds=None, report=msgs.append)
     print(f"decoder fuzz slice: fixed seeds 1000..1002, per={per}: {total} comparisons, {bad} mismatches")
     assert done == 3 and bad == 0, (f"fixed seeds 1000..1002, per={per}; replay: tests/decoder_fuzz.py run_seed(oracle, seed, {per})", msgs[:10])
-    assert total >= 3 * 270 * 2 * 3, (total, f"fixed seeds 1000..1002, per={per}")
+    assert total >= 3 * 270 * 2 * 4, (total, f"fixed seeds 1000..1002, per={per}")
     first = 2000 + int(time.time() // 86400) % 1000 * 16
     t0 = time.time()
     extra_total = extra_bad = extra_done = 0
