@@ -799,7 +799,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 // (from more than one wavefront per CU on: with at most one, single-wavefront workgroups spread evenly by themselves and keep the
                 //  dual ring stores, 8.19 vs 8.59 ms at 16 384 D2 blocks; knob decoder_wg4 = 2 takes the four-wavefront form from four wavefronts on: tests)
                 const int wg4_knob = knob(kKnobDecoderWg4);
-                const bool wg4 = mode == 0 && wg4_knob != 1 && (int64_t)grid >= 4 && (int64_t)grid > (wg4_knob == 2 ? 0 : (int64_t)cus) && (int64_t)grid <= (int64_t)cus * 8;
+                const bool wg4 = mode == 0 && wg4_knob != 1 && (int64_t)grid >= 4 && (wg4_knob == 3 || ((int64_t)grid > (wg4_knob == 2 ? 0 : (int64_t)cus) && (int64_t)grid <= (int64_t)cus * 8));   // (3: whatever the batch size -- A/B runs)
                 auto both_forms = [&](auto pol_tag) -> int {
                     constexpr int POLX = decltype(pol_tag)::value;
                     if (wg4) {

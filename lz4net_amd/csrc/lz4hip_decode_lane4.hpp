@@ -84,10 +84,15 @@ enum L4Flag { kF4Final = 1, kF4Err = 2, kF4Header = 4 };   // pending sequence: 
 //          sector of the source is fetched once instead of as two halves ~10 us apart (by then the first one's line has left the L2);
 //          bit 5 (32): ring rows are WRAPPED instead of stored twice -- no DS store ever leaves the allocation.  The library launches this
 //          instantiation on a device whose load-time probe (lds_drop_probe_kernel below) did not confirm that out-of-range stores are dropped
-template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0, class NEXT = NoNext>
+//   WAVES  wavefronts of the workgroup (1 or 4) that share `lds`: the rings of ALL of them are dword-interleaved -- row r of lane l of wavefront w at
+//          r * 256 * WAVES + (64 w + l) * 4 -- so that the ring still starts at LDS address 0 and a row stored at `row - ring size`, or past the last row,
+//          still falls outside the allocation (or into this wavefront's own flush records, see frec) whichever wavefront stores it; `wave` = w
+template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0, class NEXT = NoNext, int WAVES = 1>
 LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, const uint8_t* src, int iend,
-                                     uint8_t* dst, int oend, NEXT next = NEXT())
+                                     uint8_t* dst, int oend, NEXT next = NEXT(), int wave = 0)
 {
+    static_assert(WAVES == 1 || WAVES == 4, "one or four wavefronts per workgroup");
+    constexpr uint32_t kRow = 256u * (uint32_t)WAVES;                // bytes from one ring row to the next
     static_assert(R >= 128 && R % 16 == 0 && R <= 1008, "ring: a multiple of 16 bytes, 128 .. 1008");
     static_assert(P == 32 || P == 64, "input piece: 32 or 64 bytes");
     static_assert(FU == 64 || (FU == 128 && R >= 192), "flush unit: 64 bytes, or 128 with a ring of at least 192");
@@ -96,8 +101,8 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     static_assert(IE == 1 || (IE == 2 && FE == 2), "input requests in every iteration, or alternating with the flush");
     constexpr int RW = R / 4;                                        // ring rows (one dword per lane per row)
     constexpr bool RPOW2 = (RW & (RW - 1)) == 0;
-    constexpr uint32_t kRingBytes = (uint32_t)RW * 256u;             // the 64 rings, dword-interleaved: row r of lane l at r * 256 + l * 4
-    constexpr uint32_t kLdsBytes = lane4_lds_bytes(R);
+    constexpr uint32_t kRingBytes = (uint32_t)RW * kRow;             // the 64 * WAVES rings, dword-interleaved: row r of lane l at r * kRow + (64 * wave + l) * 4
+    constexpr uint32_t kLdsBytes = lane4_lds_bytes(R) * (uint32_t)WAVES;
     constexpr bool LS = (POL & 16) != 0;                             // L = one aligned 64-byte sector, consumed as two pieces
     constexpr int kDual = (POL & 32) ? 0 : (LZ4HIP_DEC4_DUAL_STORE); // POL bit 5: ring rows WRAPPED, no store outside the allocation (the fallback of lz4hip_api.hip)
     static_assert(!LS || P == 32, "sector input feeds 32-byte pieces");
@@ -108,8 +113,15 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
     constexpr bool kLineNoWrap = R % 64 == 0;                        // a 64-byte line of the ring (16 rows from a multiple of 16) never wraps inside
     constexpr int kNearMax = R - 20;                                 // an append writes whole dwords, up to 19 bytes past its last byte
     // vector-memory instructions per iteration: FS flush stores (if it flushes), far fetch, NL input loads (if it requests input)
-    Aligned16* const flush_rec = (Aligned16*)(lds + kRingBytes);
-    const uint32_t lane4 = (uint32_t)lane << 2;
+    // Flush record i of this wavefront.  The 512 bytes of records per wavefront lie behind the ring as TWO halves, one in each of the first two
+    // "rows" past the ring's end, at this wavefront's lanes' columns: an append's rows that run past the last ring row land in the storing
+    // wavefront's OWN records (rewritten before they are next read) or outside the allocation, never in a neighbour's.  (WAVES == 1: lds + ring + 16 i.)
+    unsigned char* const frec_base = lds + kRingBytes + (uint32_t)wave * 256u;
+    auto frec = [&](int i) -> Aligned16* {
+        if (kFlushRecs <= 16) return (Aligned16*)(frec_base + (uint32_t)i * 16u);                    // (one half suffices: the default configuration)
+        return (Aligned16*)(frec_base + (uint32_t)(i >> 4) * kRow + (uint32_t)(i & 15) * 16u);
+    };
+    const uint32_t lane4 = (uint32_t)(wave * 64 + lane) << 2;
 
     // ring-relative byte address (row * 256 | lane * 4) plus k rows, wrapped
     auto ring_add = [](uint32_t a, uint32_t rows256) -> uint32_t {
@@ -183,37 +195,37 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
             const uint32_t ob_ = oa - kRingBytes;                                                       \
             const uint32_t w1_ = wv::perm(d1_, d0_, s_), w2_ = wv::perm(d2_, d1_, s_);                  \
             if (kDual == 2) { /* two rows per LDS instruction */                                        \
-                wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, oa, w1_, w2_);                           \
-                wv::lds_store2_rows_drop<1, 2>(lds, kLdsBytes, ob_, w1_, w2_);                          \
+                wv::lds_store2_rows_drop<1 * WAVES, 2 * WAVES>(lds, kLdsBytes, oa, w1_, w2_);           \
+                wv::lds_store2_rows_drop<1 * WAVES, 2 * WAVES>(lds, kLdsBytes, ob_, w1_, w2_);          \
                 if (FOUR_) {                                                                            \
                     const uint32_t w3_ = wv::perm(d3_, d2_, s_), w4_ = wv::perm(0u, d3_, s_);           \
-                    wv::lds_store2_rows_drop<3, 4>(lds, kLdsBytes, oa, w3_, w4_);                       \
-                    wv::lds_store2_rows_drop<3, 4>(lds, kLdsBytes, ob_, w3_, w4_);                      \
+                    wv::lds_store2_rows_drop<3 * WAVES, 4 * WAVES>(lds, kLdsBytes, oa, w3_, w4_);       \
+                    wv::lds_store2_rows_drop<3 * WAVES, 4 * WAVES>(lds, kLdsBytes, ob_, w3_, w4_);      \
                 } else {                                                                                \
-                    L4_STORE2(768, wv::perm(0u, d2_, s_));                                              \
+                    L4_STORE2(3 * kRow, wv::perm(0u, d2_, s_));                                         \
                 }                                                                                       \
             } else {                                                                                    \
-                L4_STORE2(256, w1_);                                                                    \
-                L4_STORE2(512, w2_);                                                                    \
+                L4_STORE2(kRow, w1_);                                                                   \
+                L4_STORE2(2 * kRow, w2_);                                                               \
                 if (FOUR_) {                                                                            \
-                    L4_STORE2(768, wv::perm(d3_, d2_, s_));                                             \
-                    L4_STORE2(1024, wv::perm(0u, d3_, s_));                                             \
+                    L4_STORE2(3 * kRow, wv::perm(d3_, d2_, s_));                                        \
+                    L4_STORE2(4 * kRow, wv::perm(0u, d3_, s_));                                         \
                 } else {                                                                                \
-                    L4_STORE2(768, wv::perm(0u, d2_, s_));                                              \
+                    L4_STORE2(3 * kRow, wv::perm(0u, d2_, s_));                                         \
                 }                                                                                       \
             }                                                                                           \
         } else {                                                                                        \
-            const uint32_t a1_ = ring_add(oa, 256u), a2_ = ring_add(oa, 512u), a3_ = ring_add(oa, 768u); \
+            const uint32_t a1_ = ring_add(oa, kRow), a2_ = ring_add(oa, 2 * kRow), a3_ = ring_add(oa, 3 * kRow); \
             L4_RING(a1_) = wv::perm(d1_, d0_, s_);                                                      \
             L4_RING(a2_) = wv::perm(d2_, d1_, s_);                                                      \
             if (FOUR_) {                                                                                \
                 L4_RING(a3_) = wv::perm(d3_, d2_, s_);                                                  \
-                L4_RING(ring_add(oa, 1024u)) = wv::perm(0u, d3_, s_);                                   \
+                L4_RING(ring_add(oa, 4 * kRow)) = wv::perm(0u, d3_, s_);                                \
             } else {                                                                                    \
                 L4_RING(a3_) = wv::perm(0u, d2_, s_);                                                   \
             }                                                                                           \
         }                                                                                               \
-        oa = ring_add(oa, ((sb_ + (uint32_t)(n_)) << 6) & 0x700u);                                      \
+        oa = ring_add(oa, (((sb_ + (uint32_t)(n_)) << 6) & 0x700u) * (uint32_t)WAVES);                  \
         op += (n_);                                                                                     \
     } while (0)
 
@@ -283,12 +295,12 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         {
             // row of output byte op - off: (op >> 2) - ((off - (op & 3) + 3) >> 2) rows back from oa
             const uint32_t offn = kind == kK4Near ? (uint32_t)off : 4u;        // (any other kind: some valid row)
-            const uint32_t back = ((offn + 3u - ((uint32_t)op & 3u)) << 6) & ~0xFFu;
+            const uint32_t back = (((offn + 3u - ((uint32_t)op & 3u)) << 6) & ~0xFFu) * (uint32_t)WAVES;
             uint32_t sa;
             if (RPOW2) sa = (oa - back) & (kRingBytes - 1u);
             else { const uint32_t t = oa - back, u = t + kRingBytes; sa = u < t ? u : t; }
-            const uint32_t r0 = L4_RING(sa), r1 = L4_RING(ring_add(sa, 256u)), r2 = L4_RING(ring_add(sa, 512u)),
-                           r3 = L4_RING(ring_add(sa, 768u)), r4 = L4_RING(ring_add(sa, 1024u));
+            const uint32_t r0 = L4_RING(sa), r1 = L4_RING(ring_add(sa, kRow)), r2 = L4_RING(ring_add(sa, 2 * kRow)),
+                           r3 = L4_RING(ring_add(sa, 3 * kRow)), r4 = L4_RING(ring_add(sa, 4 * kRow));
             const uint32_t sr = L4_PHASE_SEL((uint32_t)op - offn);
             v0 = wv::perm(r1, r0, sr); v1 = wv::perm(r2, r1, sr); v2 = wv::perm(r3, r2, sr); v3 = wv::perm(r4, r3, sr);
         }
@@ -309,7 +321,7 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
                 if (mine) {
                     const uint64_t dp = (uint64_t)dst;
                     // ring address of the unit: fl is a multiple of 4, so it starts floor((op - fl) / 4) rows before oa's row
-                    flush_rec[frank] = Aligned16{ { ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu)), (uint32_t)fl, (uint32_t)dp, (uint32_t)(dp >> 32) } };
+                    *frec(frank) = Aligned16{ { ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu) * (uint32_t)WAVES), (uint32_t)fl, (uint32_t)dp, (uint32_t)(dp >> 32) } };
                 }
                 wv::mem_sync();
             }
@@ -322,12 +334,12 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
                 uint64_t g = 0;
                 uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                 if (act) {
-                    const Aligned16 r = flush_rec[idx];
+                    const Aligned16 r = *frec(idx);
                     g = ((uint64_t)r.w[2] | ((uint64_t)r.w[3] << 32)) + (uint64_t)(r.w[1] + 16u * (uint32_t)sub);
                     // the owner's lane bits are in r.w[0]; this helper takes rows 4*sub .. 4*sub+3 of the unit
-                    const uint32_t b0 = ring_add(r.w[0], 1024u * (uint32_t)sub);
-                    if (kLineNoWrap) { q0 = L4_RING(b0); q1 = L4_RING(b0 + 256u); q2 = L4_RING(b0 + 512u); q3 = L4_RING(b0 + 768u); }   // (immediate offsets)
-                    else { q0 = L4_RING(b0); q1 = L4_RING(ring_add(b0, 256u)); q2 = L4_RING(ring_add(b0, 512u)); q3 = L4_RING(ring_add(b0, 768u)); }
+                    const uint32_t b0 = ring_add(r.w[0], 4u * kRow * (uint32_t)sub);
+                    if (kLineNoWrap) { q0 = L4_RING(b0); q1 = L4_RING(b0 + kRow); q2 = L4_RING(b0 + 2 * kRow); q3 = L4_RING(b0 + 3 * kRow); }   // (immediate offsets)
+                    else { q0 = L4_RING(b0); q1 = L4_RING(ring_add(b0, kRow)); q2 = L4_RING(ring_add(b0, 2 * kRow)); q3 = L4_RING(ring_add(b0, 3 * kRow)); }
                 }
                 wv::vm_store16_mask(act_m, g, q0, q1, q2, q3);
             }
@@ -548,8 +560,8 @@ LZ4HIP_DEVICE int lane4_decode_block(unsigned char* lds, int lane, bool active, 
         LZ4HIP_SECTION("B5 end of block + loop");
         // ---- (B5) end of block: write out the last bytes exactly ----
         if (final_run && rem == 0 && !pv && !done) {
-            uint32_t qa = ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu));
-            while (op - fl >= 4) { const uint32_t qd = L4_RING(qa); __builtin_memcpy(dst + fl, &qd, 4); fl += 4; qa = ring_add(qa, 256u); }
+            uint32_t qa = ring_add(oa, kRingBytes - ((((uint32_t)(op - fl)) << 6) & ~0xFFu) * (uint32_t)WAVES);
+            while (op - fl >= 4) { const uint32_t qd = L4_RING(qa); __builtin_memcpy(dst + fl, &qd, 4); fl += 4; qa = ring_add(qa, kRow); }
             if (fl < op) {
                 const uint32_t qd = L4_RING(qa);
                 for (int b = 0; fl + b < op; b++) dst[fl + b] = (uint8_t)(qd >> (8 * b));
@@ -671,8 +683,8 @@ __global__ void __launch_bounds__(64) decode_lane4_kernel(Batch b, int filter, c
 // 8.4 ms for its 64 D2 blocks, two on one SIMD 10.5 each -- and where the hardware puts 1 024 single-wavefront workgroups depends on what ran
 // before them (a 65 536-block decode: 8.5 ms back to back, 10.5 ms behind the wavefront-mapped launch of the same call:
 // profiles/r06/decoder_mid_batches_placement.txt).  The four wavefronts of ONE workgroup go to the four SIMDs of one CU, and as many workgroups
-// as there are CUs spread one per CU.  The rings of the four wavefronts share one allocation, so the ring rows are WRAPPED here (POL bit 5 is
-// forced: a store at `row - ring size` would land in the neighbour's ring instead of being dropped).
+// as there are CUs spread one per CU.  The rings of the four wavefronts are interleaved row by row across all 256 lanes (WAVES = 4 of
+// lane4_decode_block), so the ring still starts at LDS address 0 and the dual ring stores keep working.
 template <bool KNOWN, int R, int P, int FU, int FS, int FE = 1, int IE = 1, int POL = 0>
 __global__ void __launch_bounds__(256) decode_lane4_wg4_kernel(Batch b, int filter)
 {
@@ -689,7 +701,7 @@ __global__ void __launch_bounds__(256) decode_lane4_wg4_kernel(Batch b, int filt
     if (!wv::any(active)) return;
     const uint8_t* src = active ? batch_src(b, blk) : nullptr;
     uint8_t* dst = active ? batch_dst(b, blk) : nullptr;
-    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL | 32>(lds_all + (size_t)w * lane4_lds_bytes(R), lane, active, src, src_len, dst, out_size);
+    const int r = lane4_decode_block<KNOWN, R, P, FU, FS, FE, IE, POL, NoNext, 4>(lds_all, lane, active, src, src_len, dst, out_size, NoNext(), w);
     if (active) b.result[blk] = r;
 }
 

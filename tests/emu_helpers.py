@@ -62,7 +62,9 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     dst = np.full((len(comps), ds), 0xA5, np.uint8)
     res = np.full(len(comps), -12345678, np.int32)
     args = (int(known), _p(src), C.c_int64(src.shape[1]), _p(sl), _p(dst), C.c_int64(ds), _p(caps), _p(res), C.c_int64(len(comps)))
-    if lane and gen == 5:                       # the persistent variant of generation 4: `lane` wavefronts in the grid
+    if lane and gen == 6:                       # generation 4 in workgroups of four wavefronts (lane = 1: dual ring stores, 2: wrapped rows)
+        lib().emu_decode_lane4_wg4(*args, 0, int(lane == 2))
+    elif lane and gen == 5:                     # the persistent variant of generation 4: `lane` wavefronts in the grid
         lib().emu_decode_lane4_persistent(*args, 0, lane)
     elif lane and gen == 4:
         lib().emu_decode_lane4(*args, 0, lane)

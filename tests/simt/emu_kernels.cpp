@@ -108,6 +108,22 @@ void emu_decode_lane4(int known, const uint8_t* src, int64_t src_stride, const i
 #undef EMU_LANE4
 }
 
+// the default configuration in workgroups of FOUR wavefronts (decode_lane4_wg4_kernel: the four rings interleaved across 256 lanes); wrapped != 0: POL bit 5
+void emu_decode_lane4_wg4(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                          int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int wrapped)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const size_t lds = 4u * lane4_lds_bytes(192);
+    if (wrapped) {
+        if (known) simt::launch(grid, block, lds, [=] { decode_lane4_wg4_kernel<true, 192, 32, 128, 2, 2, 2, 16 | 32>(b, filter); });
+        else       simt::launch(grid, block, lds, [=] { decode_lane4_wg4_kernel<false, 192, 32, 128, 2, 2, 2, 16 | 32>(b, filter); });
+    } else {
+        if (known) simt::launch(grid, block, lds, [=] { decode_lane4_wg4_kernel<true, 192, 32, 128, 2, 2, 2, 16>(b, filter); });
+        else       simt::launch(grid, block, lds, [=] { decode_lane4_wg4_kernel<false, 192, 32, 128, 2, 2, 2, 16>(b, filter); });
+    }
+}
+
 // the persistent variant of the default configuration: `groups` wavefronts whose lanes pull blocks from a counter
 void emu_decode_lane4_persistent(int known, const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
                                  int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int filter, int groups)

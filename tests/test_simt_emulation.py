@@ -12,6 +12,8 @@ SIZES = (0, 1, 12, 13, 14, 64, 65, 300, 4096, 20000, 65535, 65536)
 
 
 def _mapping(m):
+    if isinstance(m, str) and m.startswith("l4w"):                   # "l4w1" / "l4w2": the default configuration in workgroups of four wavefronts, dual ring stores / wrapped rows
+        return dict(lane=int(m[3:]), gen=6)
     if isinstance(m, str) and m.startswith("l4p"):                   # "l4p2": persistent variant of the default generation-4 configuration, 2 wavefronts
         return dict(lane=int(m[3:]), gen=5)
     if isinstance(m, str) and m.startswith("l4c"):                   # "l4c1192": fourth-generation lane decoder, ring 192 + 1000 x variant
@@ -25,7 +27,7 @@ def _mapping(m):
     return {}
 
 
-LANE3 = ["l3r128", "l3r240", "l4c27192", "l4c59192", "l4p1", "l4p3"]    # third generation (tools/ab, A/B only): a power-of-two ring and another one; the product's lane decoder: the round-4 default, the default (sector input), its persistent form with one / three wavefronts
+LANE3 = ["l3r128", "l3r240", "l4c27192", "l4c59192", "l4p1", "l4p3", "l4w1", "l4w2"]    # third generation (tools/ab, A/B only): a power-of-two ring and another one; the product's lane decoder: the round-4 default, the default (sector input), its persistent form with one / three wavefronts
 LANE3_ALL = ["l3r128", "l3r240", "l4c128", "l4c192", "l4c1192", "l4c7192", "l4c2240", "l4c5256", "l4c27192", "l4c35192", "l4c59192"]
 
 
