@@ -134,9 +134,9 @@ class Workload:
         self.used = torch.empty(n, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         # warm-up launches on slivers (module load; the lane encoder's per-device table workspace is allocated by
-        # the first batch of >= 32768 blocks), then the timed single-pass encode
+        # the first batch of >= 49152 blocks), then the timed single-pass encode
         batch.encode(self.raw[:64], batch.BLOCK, self.comp[:64], batch.BOUND, result=self.clen[:64])
-        k = min(n, 32768)
+        k = min(n, 49152)
         batch.encode(self.raw[:k], batch.BLOCK, self.comp[:k], batch.BOUND, result=self.clen[:k])
         torch.cuda.synchronize()
         self.encode_ms = min(event_ms(lambda: batch.encode(self.raw, batch.BLOCK, self.comp, batch.BOUND, result=self.clen), torch)
@@ -508,7 +508,7 @@ def main():
                 del raw, comp, back
         if not args.hc_only:
             # ---- what smaller batches get (device-resident, default dispatch): the lane mappings need the chip full, below
-            #      16 384 (decode) / 32 768 (fast encode) blocks the wavefront mappings run alone (their time is one wavefront's instruction count) ----
+            #      16 384 (decode) / 49 152 (fast encode) blocks the wavefront mappings run alone (their time is one wavefront's instruction count) ----
             torch.cuda.empty_cache()
             sweep = {}
             m_max = min(1 << 18, n)
@@ -532,7 +532,7 @@ def main():
             sweep["ok"] = last_m > 0 and batch.count_mismatches(raw_s[:last_m], back_s[:last_m], batch.BLOCK) == 0
             extras["batch_size_sweep_" + DIST_NAMES[args.dist].split("(")[0]] = sweep
             del raw_s, comp_s, back_s
-            # ---- the wavefront-mapped fast encoder on its own (what every batch below 32 768 blocks and every host-pointer slice runs; second
+            # ---- the wavefront-mapped fast encoder on its own (what every batch below 49 152 blocks and every host-pointer slice runs; second
             #      version since round 6): 65 536 blocks of both sequence-dense distributions, forced mapping, EVERY block against the CPU reference ----
             wave_enc = {}
             for d in (2, 3):

@@ -88,7 +88,7 @@ typedef struct lz4hip_batch {
 
 /* Device-resident batches: every pointer in *b is device memory of the CURRENT device; the call only
  * enqueues kernels on `stream` (a hipStream_t, NULL = default stream) and returns 0 or LZ4HIP_E_*.
- * One exception, once per device and size: the FIRST fast-encode batch of >= 32768 blocks on a device (and a later one that needs
+ * One exception, once per device and size: the FIRST fast-encode batch of >= 49152 blocks on a device (and a later one that needs
  * more resident wavefronts than any before) builds the lane encoder's table slab inside the call -- device allocations, for
  * slabs >= 2 GiB a few timed probe launches (hipEventSynchronize) on a stream of the library's own, and, when a smaller slab is
  * replaced, one hipDeviceSynchronize before that one is freed (it stays in place if the larger one cannot be had): 0.1 - 3.5 s

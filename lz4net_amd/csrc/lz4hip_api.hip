@@ -90,8 +90,8 @@ int knob(int k) { knobs_init(); return g_knob[k].load(std::memory_order_relaxed)
 // A lone wavefront of the lane mapping needs milliseconds for its 64 blocks, so the mapping only pays once the
 // batch fills the GPU (measured crossover 13 k (D2) .. 28 k (D3) blocks, profiles/r01/decode_small_batches.txt).
 constexpr int64_t kLaneDecodeMinBlocks = 16384;
-constexpr int64_t kLaneEncodeMinBlocks = 32768;  // a lane needs 60 - 110 ms for its block whatever the batch: the wavefront mapping alone is faster up to ~30 k (D2) /
-                                                // ~42 k (D3) blocks (profiles/r05/encoder_mapping_crossover.txt; until round 5: 16384)
+constexpr int64_t kLaneEncodeMinBlocks = 49152;  // a lane needs 60 - 110 ms for its block whatever the batch: the wavefront mapping alone is faster up to ~46 k (D2) /
+                                                // ~58 k (D3) blocks since its second version (profiles/r06/encoder_mapping_crossover.txt; round 5: 32768, until then 16384)
 constexpr int kLaneDecodeGeneration = 4;
 constexpr int kLane4Config = 59192;          // lane decoder: 192-byte ring, 32-byte input pieces out of whole 64-byte sectors, 128-byte flush units; iterations
                                               // alternate between flushing (two store instructions) and requesting input (four load instructions, one sector)

@@ -331,7 +331,7 @@ def test_concurrent_streams_share_the_workspace_safely(torch_cuda, oracle):
     import threading
     torch = torch_cuda
     from lz4net_amd import batch
-    n, length = 32768, 4096                                          # (>= 32768 blocks: the default dispatch launches the lane mapping too)
+    n, length = 49152, 4096                                          # (>= 49152 blocks: the default dispatch launches the lane mapping too)
     bound = length + length // 255 + 16
     errors = []
 

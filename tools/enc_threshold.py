@@ -12,7 +12,7 @@ for dist in (2, 3):
     with _lib.tuning(encoder="lane"):
         batch.encode(raw, batch.BLOCK, comp, batch.BOUND)          # (the slab at its final size)
     torch.cuda.synchronize()
-    for n in (12288, 16384, 20480, 24576, 32768, 49152, 65536):
+    for n in (16384, 24576, 32768, 40960, 49152, 57344, 65536):
         out = {}
         for name in ("wave", "lane"):
             _lib.tuning_set("encoder", name)
