@@ -164,8 +164,8 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *   "encoder_wave_version"       [LZ4HIP_ENCODER_WAVE_VERSION]  wavefront-mapped fast encoder, blocks below LZ4_64KLIMIT: 0 = default 2 (encode_fast_block64k, round 6);
  *                                 1 = the first version (exists in -DLZ4HIP_TUNING_BUILD libraries only: A/B runs)
  *   "decoder_wg4"                [LZ4HIP_DECODER_WG4]  lane decoder, batches of at most one residency round: 0 = default, workgroups of FOUR wavefronts (they go to the four SIMDs of
- *                                 one CU, whatever ran on the device before) while the batch has more than one and at most eight wavefronts per CU; 1 = always workgroups of one
- *                                 wavefront; 2 = the four-wavefront form from four wavefronts on (tests)
+ *                                 one CU, whatever ran on the device before) while the batch has more than one wavefront per CU and at most one residency round; 1 = always workgroups of one
+ *                                 wavefront; 2 = the four-wavefront form from four wavefronts on (tests); 3 = whatever the batch size (A/B runs)
  *   "decoder_wrapped_stores"     [LZ4HIP_DECODER_WRAPPED_STORES]  lane decoder: its default instantiation stores every ring row at `row` and at `row - ring size`
  *                                 and relies on gfx950 dropping the LDS store that falls outside the workgroup's allocation; the library CHECKS that rule once per
  *                                 device before the first lane-mapped decode (a ~1 ms probe launch) and uses the instantiation that wraps its rows instead (same bytes,

@@ -68,7 +68,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
     { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2; 1 = the calling thread's pipeline alone, rounds 2-5)
-    { "decoder_wg4", "LZ4HIP_DECODER_WG4", false },                   // lane decoder, batches of at most one residency round: 0 default = workgroups of FOUR wavefronts (one per SIMD of a CU) while the batch has more than one and at most eight wavefronts per CU; 1 = always workgroups of one wavefront (rounds 1-5); 2 = the four-wavefront form from four wavefronts on (tests)
+    { "decoder_wg4", "LZ4HIP_DECODER_WG4", false },                   // lane decoder, batches of at most one residency round: 0 default = workgroups of FOUR wavefronts (one per SIMD of a CU) while the batch has more than one wavefront per CU and at most one residency round; 1 = always workgroups of one wavefront (rounds 1-5); 2 = the four-wavefront form from four wavefronts on (tests); 3 = whatever the batch size (A/B runs)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
 std::atomic<int> g_knob[kKnobCount];
@@ -799,7 +799,7 @@ int launch_decode(const lz4hip_batch_t* b, int known, hipStream_t stream)
                 // (from more than one wavefront per CU on: with at most one, single-wavefront workgroups spread evenly by themselves and keep the
                 //  dual ring stores, 8.19 vs 8.59 ms at 16 384 D2 blocks; knob decoder_wg4 = 2 takes the four-wavefront form from four wavefronts on: tests)
                 const int wg4_knob = knob(kKnobDecoderWg4);
-                const bool wg4 = mode == 0 && wg4_knob != 1 && (int64_t)grid >= 4 && (wg4_knob == 3 || ((int64_t)grid > (wg4_knob == 2 ? 0 : (int64_t)cus) && (int64_t)grid <= (int64_t)cus * 8));   // (3: whatever the batch size -- A/B runs)
+                const bool wg4 = mode == 0 && wg4_knob != 1 && (int64_t)grid >= 4 && (wg4_knob == 3 || ((int64_t)grid > (wg4_knob == 2 ? 0 : (int64_t)cus) && (int64_t)grid <= capacity));   // (up to one residency round; 3: whatever the batch size -- A/B runs)
                 auto both_forms = [&](auto pol_tag) -> int {
                     constexpr int POLX = decltype(pol_tag)::value;
                     if (wg4) {
