@@ -468,7 +468,7 @@ def test_fast_encode_default_dispatch_two_launches(torch_cuda, oracle):
     sampled, whichever kernel finished it."""
     torch = torch_cuda
     from lz4net_amd import _lib, batch
-    per = 8192
+    per = 12288                                                      # (4 x 12288 = 49152 blocks: from there on the default dispatch launches both mappings)
     parts = [batch.synth(d, 4242, 0, per) for d in (1, 2, 3, 0)]
     raw = torch.cat(parts, dim=0)
     n = raw.shape[0]
