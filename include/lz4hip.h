@@ -163,6 +163,9 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 kernels and copies fill the other's gaps (0 = default 2; 1 = the calling thread's own pipeline alone; at most 8)
  *   "encoder_wave_version"       [LZ4HIP_ENCODER_WAVE_VERSION]  wavefront-mapped fast encoder, blocks below LZ4_64KLIMIT: 0 = default 2 (encode_fast_block64k, round 6);
  *                                 1 = the first version (exists in -DLZ4HIP_TUNING_BUILD libraries only: A/B runs)
+ *   "encoder_wg5"                [LZ4HIP_ENCODER_WG5]  wavefront-mapped fast encoder: 0 = default, workgroups of FIVE blocks (five wavefronts, 80 KiB of LDS; two per CU = ten
+ *                                 blocks) wherever that saves the batch a residency round (2 305 - 2 560 blocks, 16 384, everything from 23 040 blocks up on 256 CUs) -- gfx950 hands out LDS in granules of 1 280 bytes, a 16 KiB table takes thirteen of a
+ *                                 CU's 128, so only nine one-block workgroups fit; 1 = always one block per workgroup (rounds 1-5); 2 = five per workgroup whatever the size
  *   "decoder_wg4"                [LZ4HIP_DECODER_WG4]  lane decoder, batches of at most one residency round: 0 = default, workgroups of FOUR wavefronts (they go to the four SIMDs of
  *                                 one CU, whatever ran on the device before) while the batch has more than one wavefront per CU and at most one residency round; 1 = always workgroups of one
  *                                 wavefront; 2 = the four-wavefront form from four wavefronts on (tests); 3 = whatever the batch size (A/B runs)

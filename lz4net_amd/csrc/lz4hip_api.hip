@@ -50,7 +50,7 @@ void count_dispatch(int k) { g_dispatch[k].fetch_add(1, std::memory_order_relaxe
 // first time any knob is looked at; after that the launch paths read an atomic and never call getenv().
 // Mappings: 0 = automatic, 1 = one wavefront per block, 2 = one lane per block.
 enum Knob { kKnobDecoder = 0, kKnobEncoder, kKnobHc, kKnobEncoderWavesPerCu, kKnobHcWavesPerCu, kKnobHcGroups,
-            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobHostWorkers, kKnobDecoderWg4, kKnobDecoderWrappedStores, kKnobCount };
+            kKnobHostThreads, kKnobHostSlices, kKnobLogicalDevices, kKnobDecoderGen, kKnobDecoderRing, kKnobHcGen, kKnobHcCtrlEvery, kKnobHcCtrlLanes, kKnobHcSubChunks, kKnobDecoderPersist, kKnobDecoderGroups, kKnobEncoderSlabTries, kKnobEncoderWaveVersion, kKnobEncoderWg5, kKnobHostWorkers, kKnobDecoderWg4, kKnobDecoderWrappedStores, kKnobCount };
 struct KnobInfo { const char* name; const char* env; bool mapping; };
 const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder", "LZ4HIP_DECODER", true }, { "encoder", "LZ4HIP_ENCODER", true }, { "hc", "LZ4HIP_HC", true },
@@ -67,6 +67,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "decoder_groups", "LZ4HIP_DECODER_GROUPS", false },           // tests: wavefronts of the persistent lane decoder's grid (0 = the residency): few lanes, many restarts each
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
+    { "encoder_wg5", "LZ4HIP_ENCODER_WG5", false },                   // wavefront-mapped fast encoder: 0 default = workgroups of FIVE blocks (80 KiB of LDS: two per CU = ten blocks) wherever that saves a residency round against one-block workgroups (nine per CU: 16 KiB is thirteen of the CU's 128 LDS granules of 1 280 bytes); 1 = always one block per workgroup (rounds 1-5); 2 = five per workgroup whatever the batch size (tests, A/B runs)
     { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2; 1 = the calling thread's pipeline alone, rounds 2-5)
     { "decoder_wg4", "LZ4HIP_DECODER_WG4", false },                   // lane decoder, batches of at most one residency round: 0 default = workgroups of FOUR wavefronts (one per SIMD of a CU) while the batch has more than one wavefront per CU and at most one residency round; 1 = always workgroups of one wavefront (rounds 1-5); 2 = the four-wavefront form from four wavefronts on (tests); 3 = whatever the batch size (A/B runs)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
@@ -398,6 +399,22 @@ struct HcPipe {
 };
 HcPipe g_hc_pipe[64];
 
+// Whether the wavefront-mapped fast encoder runs as workgroups of kEncodeBlocksPerGroup blocks (ten blocks per CU) instead of one-block workgroups
+// (nine per CU): whenever that saves a residency round -- 2 305 ... 2 560 blocks on 256 CUs, 16 384 (7 rounds instead of 8), every batch from 90 blocks
+// per CU up.  With the same number of rounds one block per workgroup is the better form (finer placement, nine wavefronts per CU disturb one another
+// less than ten): profiles/r06/wave_encoder_round_steps.txt.
+constexpr int kEncodeBlocksPerGroup = 5;
+bool encoder_five_blocks_per_workgroup(int64_t n_blocks)
+{
+    const int k = knob(kKnobEncoderWg5);
+    if (k == 1 || n_blocks < kEncodeBlocksPerGroup) return false;
+    if (k == 2) return true;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
+    const int64_t rounds9 = (n_blocks + 9 * cus - 1) / (9 * cus), rounds10 = (n_blocks + 10 * cus - 1) / (10 * cus);
+    return rounds10 < rounds9;
+}
+
 int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
 {
     if (b->n_blocks == 0) return 0;
@@ -441,6 +458,21 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
                 hipLaunchKernelGGL(encode_fast_kernel<1>, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, pick == 'a' ? (int)kEncodeMayDefer : 0);
             else
 #endif
+            if (encoder_five_blocks_per_workgroup(d.n_blocks)) {
+                // gfx950 hands out LDS in granules of 1 280 bytes, 128 per CU: a 16 KiB table takes thirteen, so NINE one-block workgroups fit a CU;
+                // five tables are exactly 64 granules, two such workgroups fill the CU with TEN blocks (profiles/r06/wave_encoder_round_steps.txt)
+                static std::atomic<bool> attr_set[64];
+                int dev5 = 0;
+                HIP_TRY(hipGetDevice(&dev5));
+                if (dev5 < 0 || dev5 >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
+                if (!attr_set[dev5].load(std::memory_order_acquire)) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)(encode_fast_kernel<2, kEncodeBlocksPerGroup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kEncodeBlocksPerGroup * kFastTableBytes));
+                    attr_set[dev5].store(true, std::memory_order_release);
+                }
+                hipLaunchKernelGGL((encode_fast_kernel<2, kEncodeBlocksPerGroup>), dim3((unsigned)((d.n_blocks + kEncodeBlocksPerGroup - 1) / kEncodeBlocksPerGroup)),
+                                   dim3(64 * kEncodeBlocksPerGroup), kEncodeBlocksPerGroup * kFastTableBytes, stream, d, pick == 'a' ? (int)kEncodeMayDefer : 0);
+            } else
             hipLaunchKernelGGL(encode_fast_kernel<2>, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d,
                                pick == 'a' ? (int)kEncodeMayDefer : 0);
             HIP_TRY(hipGetLastError());

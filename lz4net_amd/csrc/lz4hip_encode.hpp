@@ -522,12 +522,17 @@ tail:
 // LZ4_64KLIMIT made of short sequences get kDeferredResult instead of being finished (a second launch takes them).
 enum EncodeKernelFlags { kEncodeOnlyGeneric = 1, kEncodeMayDefer = 2 };
 // V64K: which version of the 64k encoder runs (2 = encode_fast_block64k, the product; 1 = the first version, instantiated in tuning builds only: A/B runs)
-template <int V64K = 2>
-__global__ void __launch_bounds__(64) encode_fast_kernel(Batch b, int flags)
+// WAVES: wavefronts (= blocks) per workgroup, each with its own 16 KiB of the workgroup's dynamic LDS.  gfx950 allocates LDS in granules of 1 280 bytes
+// (128 per CU): one table = 13 granules = nine one-block workgroups per CU, five tables = 64 granules exactly = two workgroups = TEN blocks per CU.
+// The launch site picks 5 wherever that saves a residency round (lz4hip_api.hip: encoder_five_blocks_per_workgroup); no barrier anywhere: the
+// wavefronts of a workgroup share nothing but the allocation.
+template <int V64K = 2, int WAVES = 1>
+__global__ void __launch_bounds__(64 * WAVES) encode_fast_kernel(Batch b, int flags)
 {
     const int only_generic = flags & kEncodeOnlyGeneric;
-    LZ4HIP_DYN_LDS(lds);
-    const int64_t blk = (int64_t)blockIdx.x;
+    LZ4HIP_DYN_LDS(lds_all);
+    unsigned char* const lds = lds_all + (WAVES > 1 ? (size_t)wv::wave_in_block() * kFastTableBytes : 0);
+    const int64_t blk = WAVES > 1 ? (int64_t)blockIdx.x * WAVES + wv::wave_in_block() : (int64_t)blockIdx.x;
     if (blk >= b.n_blocks) return;
     const int n = wv::uniform(batch_src_len(b, blk));
     if (only_generic && n < k64kLimit) return;

@@ -80,7 +80,7 @@ def decode(comps, out_sizes, known=True, src_lens=None, waves_per_group=1, auto=
     return res, dst
 
 
-def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=False, lcp=False):
+def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=False, lcp=False, wg5=False):
     src, sl = pack(blocks)
     if caps is None:
         caps = [len(b) + len(b) // 255 + 16 for b in blocks]
@@ -101,6 +101,8 @@ def encode(blocks, caps=None, hc=False, groups=2, lane=False, conv=False, nat=Fa
         lib().emu_encode_hc(*args, groups, int(max(len(b) for b in blocks) > 65536))
     elif lane:
         lib().emu_encode_fast_lane(*args, 1)
+    elif wg5:
+        lib().emu_encode_fast_wg5(*args)
     else:
         lib().emu_encode_fast(*args)
     return res, dst

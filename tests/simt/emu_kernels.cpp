@@ -144,6 +144,14 @@ void emu_encode_fast(const uint8_t* src, int64_t src_stride, const int32_t* src_
     simt::launch(dim3((unsigned)n), dim3(64), kFastTableBytes, [=] { encode_fast_kernel(b, 0); });
 }
 
+// launch_encode's form for batches of more than nine blocks per CU: five blocks per workgroup, each wavefront with its own 16 KiB of the allocation
+void emu_encode_fast_wg5(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
+                         int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n)
+{
+    Batch b = make_batch(src, src_stride, src_len, dst, dst_stride, dst_cap, result, n);
+    simt::launch(dim3((unsigned)((n + 4) / 5)), dim3(64 * 5), 5 * kFastTableBytes, [=] { encode_fast_kernel<2, 5>(b, 0); });
+}
+
 #ifdef LZ4HIP_HAVE_HC
 void emu_encode_hc(const uint8_t* src, int64_t src_stride, const int32_t* src_len, uint8_t* dst,
                    int64_t dst_stride, const int32_t* dst_cap, int32_t* result, int64_t n, int groups, int heads32)

@@ -80,6 +80,7 @@ def test_fast_encode_wave_second_version_paths(gpu, oracle):
     equal bytes and the byte-wise form near the end of a block, the merged catch-up + count loads, the one-store sequence emit next to the
     general one -- sizes around every threshold, dense / sparse / periodic / long-run data, exact and too-small output limits.  The twin of
     tests/test_simt_emulation.py::test_encode_fast64k_window_wide_count_and_single_store_paths, through the C ABI with the mapping forced."""
+    from lz4net_amd import _lib
     rng = np.random.default_rng(606)
     blocks = []
     for n in list(range(13, 40)) + [255, 256, 257, 260, 261, 262, 263, 268, 269, 270, 300, 511, 512, 513, 517, 518, 519, 777, 1200, 5000, 33333, 65536, 65546]:
@@ -98,11 +99,13 @@ def test_fast_encode_wave_second_version_paths(gpu, oracle):
         blocks.append(b)
     want = [oracle.compress(a) for a in blocks]
     with ForcedMapping("LZ4HIP_ENCODER", "wave"):
-        res, dst = gpu.encode(blocks)
-        for i, (a, w) in enumerate(zip(blocks, want)):
-            assert res[i] == len(w), (i, a.size, res[i], len(w))
-            assert np.array_equal(dst[i, :res[i]], w), (i, a.size)
-            assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
+        for wg5 in (1, 2, 0):           # one block per workgroup, five per workgroup (the form of batches > nine blocks per CU; here with a ragged last workgroup), the default
+            with _lib.tuning(encoder_wg5=wg5):
+                res, dst = gpu.encode(blocks if wg5 != 2 else blocks[:len(blocks) - (len(blocks) % 5 == 0)])
+            for i, (a, w) in enumerate(zip(blocks[:len(res)], want)):
+                assert res[i] == len(w), (wg5, i, a.size, res[i], len(w))
+                assert np.array_equal(dst[i, :res[i]], w), (wg5, i, a.size)
+                assert (dst[i, a.size + a.size // 255 + 16:] == 0xA5).all()
         for delta in (0, -1, -3, -9):
             caps = [max(len(w) + delta, 0) for w in want]
             res, dst = gpu.encode(blocks, caps=caps)

@@ -108,10 +108,12 @@ def test_decode_error_codes_match_oracle(oracle, lane):
         assert (dst[i, max(cases_u[i][2], 0):] == 0xA5).all()
 
 
-@pytest.mark.parametrize("lane", [False, True], ids=["wave-per-block", "lane-per-block"])
+@pytest.mark.parametrize("lane", [False, True, "wg5"], ids=["wave-per-block", "lane-per-block", "five-blocks-per-workgroup"])
 def test_encode_fast_bit_exact(oracle, lane):
-    blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6) if lane else (5,))
-    res, dst = emu.encode(blocks, lane=lane)
+    blocks = _blocks(oracle, sizes=SIZES + (65546, 65547, 70000), seeds=(5, 6) if lane is True else (5,))
+    if lane == "wg5":
+        blocks = blocks[:len(blocks) - (len(blocks) % 5 == 0)]       # a last workgroup with idle wavefronts
+    res, dst = emu.encode(blocks, lane=lane is True, wg5=lane == "wg5")
     for i, a in enumerate(blocks):
         want = oracle.compress(a)
         assert res[i] == len(want), (i, a.size, res[i], len(want))
