@@ -98,8 +98,10 @@ typedef struct lz4hip_batch {
 int lz4hip_encode_batch_device(const lz4hip_batch_t* b, int mode, void* stream);
 int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, void* stream);
 
-/* Host-resident batches: stages through device memory (H2D, kernels, D2H) and synchronises.  Batches of >= 8192 blocks (not LZ4HC) are cut
- * round-robin over two staging pipelines on the current device, each on a persistent worker thread of the library (knob host_workers). */
+/* Host-resident batches: stages through device memory (H2D, kernels, D2H) in slices whose copies and kernels overlap, and synchronises.  DECODE
+ * batches of >= 8192 blocks are cut round-robin over two staging pipelines on the current device, each on a persistent worker thread of the
+ * library (knob host_workers); fast-ENCODE batches run as one pipeline whose slices are equal and at most one residency round of the
+ * wavefront-mapped encoder each (ten blocks per CU): its kernels are the bottleneck. */
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode);
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size);
 
@@ -160,7 +162,8 @@ int lz4hip_dispatch_counts(uint64_t* counts, int n);
  *                                 "encoder_slab_chunks" (separate allocations the slab in use consists of)
  *   "host_workers"               [LZ4HIP_HOST_WORKERS]  host-pointer batches of >= 8192 blocks on ONE device (lz4hip_*_batch_host; not LZ4HC) run as this many staging
  *                                 pipelines that share the device -- the persistent workers of the *_multi entry points, block i -> worker i mod k -- so that one pipeline's
- *                                 kernels and copies fill the other's gaps (0 = default 2; 1 = the calling thread's own pipeline alone; at most 8)
+ *                                 kernels and copies fill the other's gaps (0 = default: 2 for decode, 1 for fast encode, whose kernels are the bottleneck either way;
+ *                                 1 = the calling thread's own pipeline alone; at most 8)
  *   "encoder_wave_version"       [LZ4HIP_ENCODER_WAVE_VERSION]  wavefront-mapped fast encoder, blocks below LZ4_64KLIMIT: 0 = default 2 (encode_fast_block64k, round 6);
  *                                 1 = the first version (exists in -DLZ4HIP_TUNING_BUILD libraries only: A/B runs)
  *   "encoder_wg5"                [LZ4HIP_ENCODER_WG5]  wavefront-mapped fast encoder: 0 = default, workgroups of FIVE blocks (five wavefronts, 80 KiB of LDS; two per CU = ten

@@ -68,7 +68,7 @@ const KnobInfo kKnobInfo[kKnobCount] = {
     { "encoder_slab_tries", "LZ4HIP_ENCODER_SLAB_TRIES", false },   // lane encoder's table slab: candidate placements that are built and measured (0 default = 4; 1 = the first one, unmeasured)
     { "encoder_wave_version", "LZ4HIP_ENCODER_WAVE_VERSION", false },   // wavefront-mapped fast encoder, blocks < 64 KiB + 11: 0 default = 2 (encode_fast_block64k); 1 = the first version, in LZ4HIP_TUNING_BUILD libraries only
     { "encoder_wg5", "LZ4HIP_ENCODER_WG5", false },                   // wavefront-mapped fast encoder: 0 default = workgroups of FIVE blocks (80 KiB of LDS: two per CU = ten blocks) wherever that saves a residency round against one-block workgroups (nine per CU: 16 KiB is thirteen of the CU's 128 LDS granules of 1 280 bytes); 1 = always one block per workgroup (rounds 1-5); 2 = five per workgroup whatever the batch size (tests, A/B runs)
-    { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2; 1 = the calling thread's pipeline alone, rounds 2-5)
+    { "host_workers", "LZ4HIP_HOST_WORKERS", false },                 // single-device host-pointer batches of >= 8192 blocks: staging pipelines (persistent worker threads) that share the device, each taking every k-th block (0 default = 2 for decode, 1 for the encoders; 1 = the calling thread's pipeline alone, rounds 2-5)
     { "decoder_wg4", "LZ4HIP_DECODER_WG4", false },                   // lane decoder, batches of at most one residency round: 0 default = workgroups of FOUR wavefronts (one per SIMD of a CU) while the batch has more than one wavefront per CU and at most one residency round; 1 = always workgroups of one wavefront (rounds 1-5); 2 = the four-wavefront form from four wavefronts on (tests); 3 = whatever the batch size (A/B runs)
     { "decoder_wrapped_stores", "LZ4HIP_DECODER_WRAPPED_STORES", false },   // lane decoder: 1 = the instantiation that WRAPS its ring rows (no LDS store outside the allocation) whatever the device's probe said; 0 default = what the probe allows (read-only twin: "decoder_dual_store")
 };
@@ -1179,7 +1179,14 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
     per_slice = per_slice > hi ? hi : per_slice;
     per_slice = per_slice < 1 ? 1 : (per_slice > n ? n : per_slice);
     const size_t m = (size_t)per_slice;
-    const int64_t n_slices = (n + per_slice - 1) / per_slice;
+    // The slice table (equal slices; a quarter slice at both ends -- less time before the first kernel and after the last one -- measured
+    // no gain: profiles/r06/host_tapered_slices_ab.txt, tools/ab/host_tapered_slices.patch).
+    std::vector<int64_t> bounds;
+    try {
+        for (int64_t at = 0; at < n; at += per_slice) bounds.push_back(at);
+        bounds.push_back(n);
+    } catch (const std::bad_alloc&) { return fail(LZ4HIP_E_MEMORY, "out of host memory"); }
+    const int64_t n_slices = (int64_t)bounds.size() - 1;
     const int slots = n_slices < kHostSlots ? (int)n_slices : kHostSlots;
     // device and pinned "in" image: [src slots | src_len | dst_cap];  "out" image: [dst slots | result]
     const size_t in_lens = align_up(s_stride * m, 256), in_caps = in_lens + align_up(4 * m, 256), in_bytes = in_caps + align_up(4 * m, 256);
@@ -1241,18 +1248,15 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
     auto drain_one = [&]() {                                         // (blocking)
         const int slot = (int)(drained % slots);
         PIPE_TRY(hipEventSynchronize(pp.e_out[slot]));
-        if (!err) {
-            const int64_t first = drained * per_slice;
-            scatter(first, n - first < per_slice ? n - first : per_slice, slot);
-        }
+        if (!err) scatter(bounds[(size_t)drained], bounds[(size_t)drained + 1] - bounds[(size_t)drained], slot);
         drained++;
     };
     // whatever the caller queued on its stream before this call comes first
     PIPE_TRY(hipEventRecord(pp.e_start, hipStreamPerThread));
     PIPE_TRY(hipStreamWaitEvent(pp.s_in, pp.e_start, 0));
     int64_t slice = 0;
-    for (int64_t first = 0; first < n && !err; first += per_slice, slice++) {
-        const int64_t cnt = n - first < per_slice ? n - first : per_slice;
+    for (; slice < n_slices && !err; slice++) {
+        const int64_t first = bounds[(size_t)slice], cnt = bounds[(size_t)slice + 1] - first;
         const int slot = (int)(slice % slots);
         while (!err && drained + slots <= slice) drain_one();        // the slot's previous slice must be out of its buffers
         scatter_wait(slot);                                          // ... and in the caller's
@@ -1266,7 +1270,9 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
             if (sl > 0) memcpy(pi + s_stride * (size_t)j, src_row(first + j), (size_t)sl);
         });
         // copy in (the slot's previous kernels have finished: their slice has been drained)
-        PIPE_TRY(hipMemcpyAsync(d_in[slot], pi, in_bytes, hipMemcpyHostToDevice, pp.s_in));
+        // (the rows the slice has, then its lengths and capacities: a short slice does not pay for a full one's image)
+        PIPE_TRY(hipMemcpyAsync(d_in[slot], pi, s_stride * (size_t)cnt, hipMemcpyHostToDevice, pp.s_in));
+        PIPE_TRY(hipMemcpyAsync(d_in[slot] + in_lens, pi + in_lens, in_bytes - in_lens, hipMemcpyHostToDevice, pp.s_in));
         PIPE_TRY(hipEventRecord(pp.e_in[slot], pp.s_in));
         // kernels, on the slot's own stream: after their input has landed
         hipStream_t ks = pp.s_k[slot];
@@ -1280,7 +1286,8 @@ int run_host_batch(const lz4hip_batch_t* hb, bool dst_len_is_result, Run run, in
         PIPE_TRY(hipEventRecord(pp.e_k[slot], ks));
         // copy out: after the kernels
         PIPE_TRY(hipStreamWaitEvent(pp.s_out, pp.e_k[slot], 0));
-        PIPE_TRY(hipMemcpyAsync(g_pin_out[slot].p, d_out[slot], out_bytes, hipMemcpyDeviceToHost, pp.s_out));
+        PIPE_TRY(hipMemcpyAsync(g_pin_out[slot].p, d_out[slot], d_stride * (size_t)cnt, hipMemcpyDeviceToHost, pp.s_out));
+        PIPE_TRY(hipMemcpyAsync((uint8_t*)g_pin_out[slot].p + out_res, d_out[slot] + out_res, out_bytes - out_res, hipMemcpyDeviceToHost, pp.s_out));
         PIPE_TRY(hipEventRecord(pp.e_out[slot], pp.s_out));
         if (err) break;
         // slices that have already arrived are scattered while the later ones are in flight
@@ -1586,21 +1593,40 @@ int lz4hip_decode_batch_device(const lz4hip_batch_t* b, int known_output_size, v
 // D2 decode 23.6 -> 33.5 GB/s on the driver's box of round 5/6 (profiles/r06/bench_driver_style_call1.json, host_pointer_batch_multi_device).
 // Knob host_workers: 1 = the calling thread's pipeline alone.
 constexpr int64_t kHostWorkersMinBlocks = 8192;
-int host_workers_for(const lz4hip_batch_t* b, int mode_is_hc)
+int host_workers_for(const lz4hip_batch_t* b, int mode_is_hc)                  // (decode; fast encode only where the knob is set)
 {
     if (!b || b->n_blocks < kHostWorkersMinBlocks || mode_is_hc) return 1;
     const int k = knob(kKnobHostWorkers);
     return k > 0 ? (k > 8 ? 8 : k) : 2;
 }
 
+// Slices of a host-pointer FAST encode: the wavefront-mapped encoder holds ten blocks per CU (workgroups of five) and a slice's kernel time goes by
+// whole residency rounds -- 2 731 blocks (a sixth of 16 384) are 10.7 per CU = two rounds, 12.5 ms, where 2 560 blocks take 7.6 ms.  So a batch is cut
+// into the fewest EQUAL slices of at most one round each (16 384 blocks: 7 x 2 341), and it runs as ONE pipeline: the kernels are the bottleneck, a
+// second pipeline's slices only compete for the same ten places per CU (16 384 blocks 15.7-16.4 against 11.1-13.8 GB/s with two pipelines and 11.9-14.4
+// with round 5's six equal slices, three runs each on one box: profiles/r06/host_encode_one_pipeline_equal_round_slices.txt; earlier forms of the rule:
+// host_encode_slices_of_one_residency_round.txt, host_tapered_slices_ab.txt).
+int64_t encode_host_slice_blocks(const lz4hip_batch_t* b, int mode)
+{
+    if (mode == LZ4HIP_MODE_HC) return kHcHostSliceBlocks;
+    int dev = 0, cus = 0;
+    if (!b || b->n_blocks < 4096 || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const int64_t round = (int64_t)2 * kEncodeBlocksPerGroup * cus, slices = (b->n_blocks + round - 1) / round;
+    return (b->n_blocks + slices - 1) / slices;
+}
+
 int lz4hip_encode_batch_host(const lz4hip_batch_t* b, int mode)
 {
-    const int workers = host_workers_for(b, mode == LZ4HIP_MODE_HC);
+    // (two pipelines only where the knob asks for them: see above)
+    const int workers = mode == LZ4HIP_MODE_HC || knob(kKnobHostWorkers) <= 0 ? 1 : host_workers_for(b, 0);
+    const int64_t slice = encode_host_slice_blocks(b, mode);
     int dev = 0;
     if (workers > 1 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
-        return run_host_batch_multi(b, true, 1ull << dev, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); }, 0, workers);
-    return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); },
-                          mode == LZ4HIP_MODE_HC ? kHcHostSliceBlocks : 0);
+        return run_host_batch_multi(b, true, 1ull << dev, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); }, slice, workers);
+    return run_host_batch(b, true, [mode](const lz4hip_batch_t* db, hipStream_t s) { return launch_encode(db, mode, s); }, slice);
 }
 
 int lz4hip_decode_batch_host(const lz4hip_batch_t* b, int known_output_size)
