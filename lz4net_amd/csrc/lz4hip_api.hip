@@ -453,28 +453,35 @@ int launch_encode(const lz4hip_batch_t* b, int mode, hipStream_t stream)
             if (!ws) { lease.lock.unlock(); pick = 'w'; }
         }
         if (pick != 'l') {
+            bool first_version = false;
 #ifdef LZ4HIP_TUNING_BUILD
-            if (knob(kKnobEncoderWaveVersion) == 1)
+            first_version = knob(kKnobEncoderWaveVersion) == 1;
+            if (first_version)
                 hipLaunchKernelGGL(encode_fast_kernel<1>, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, pick == 'a' ? (int)kEncodeMayDefer : 0);
-            else
 #endif
-            if (encoder_five_blocks_per_workgroup(d.n_blocks)) {
-                // gfx950 hands out LDS in granules of 1 280 bytes, 128 per CU: a 16 KiB table takes thirteen, so NINE one-block workgroups fit a CU;
-                // five tables are exactly 64 granules, two such workgroups fill the CU with TEN blocks (profiles/r06/wave_encoder_round_steps.txt)
-                static std::atomic<bool> attr_set[64];
+            // gfx950 hands out LDS in granules of 1 280 bytes, 128 per CU: a 16 KiB table takes thirteen, so NINE one-block workgroups fit a CU;
+            // five tables are exactly 64 granules, two such workgroups fill the CU with TEN blocks (profiles/r06/wave_encoder_round_steps.txt).
+            // 80 KiB of dynamic LDS has to be allowed per device first; where that is refused the one-block form runs.
+            bool five = !first_version && encoder_five_blocks_per_workgroup(d.n_blocks);
+            if (five) {
+                static std::atomic<int> attr_state[64];                  // 0 not asked yet, 1 allowed, 2 refused
                 int dev5 = 0;
                 HIP_TRY(hipGetDevice(&dev5));
                 if (dev5 < 0 || dev5 >= 64) return fail(LZ4HIP_E_DEVICE, "device index out of range");
-                if (!attr_set[dev5].load(std::memory_order_acquire)) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)(encode_fast_kernel<2, kEncodeBlocksPerGroup>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                kEncodeBlocksPerGroup * kFastTableBytes));
-                    attr_set[dev5].store(true, std::memory_order_release);
+                int st = attr_state[dev5].load(std::memory_order_acquire);
+                if (st == 0) {
+                    st = hipFuncSetAttribute((const void*)(encode_fast_kernel<2, kEncodeBlocksPerGroup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kEncodeBlocksPerGroup * kFastTableBytes) == hipSuccess ? 1 : 2;
+                    if (st == 2) (void)hipGetLastError();
+                    attr_state[dev5].store(st, std::memory_order_release);
                 }
+                five = st == 1;
+            }
+            if (five)
                 hipLaunchKernelGGL((encode_fast_kernel<2, kEncodeBlocksPerGroup>), dim3((unsigned)((d.n_blocks + kEncodeBlocksPerGroup - 1) / kEncodeBlocksPerGroup)),
                                    dim3(64 * kEncodeBlocksPerGroup), kEncodeBlocksPerGroup * kFastTableBytes, stream, d, pick == 'a' ? (int)kEncodeMayDefer : 0);
-            } else
-            hipLaunchKernelGGL(encode_fast_kernel<2>, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d,
-                               pick == 'a' ? (int)kEncodeMayDefer : 0);
+            else if (!first_version)
+                hipLaunchKernelGGL(encode_fast_kernel<2>, dim3((unsigned)d.n_blocks), dim3(64), kFastTableBytes, stream, d, pick == 'a' ? (int)kEncodeMayDefer : 0);
             HIP_TRY(hipGetLastError());
             count_dispatch(LZ4HIP_K_ENCODE_WAVE);
         }
