@@ -342,6 +342,39 @@ def test_host_batch_many_slices_and_layouts(gpu, oracle):
     assert (used == res).all() and all(np.array_equal(back[i, :sizes[i]], raw_rows[i, :sizes[i]]) for i in range(0, n, 13))
 
 
+def test_host_fast_encode_default_slices_of_one_residency_round(gpu, oracle):
+    """A host-pointer fast encode of 4 096 blocks or more is cut, by default, into the fewest EQUAL slices of at most one residency round of the
+    wavefront-mapped encoder (ten blocks per CU; lz4hip_api.hip: encode_host_slice_blocks) and runs as one pipeline; a slice's copies move only the
+    rows it has.  5 203 blocks (three slices, the last one shorter) with some ragged rows: every result and a sample of the payloads against the
+    oracle, canaries behind every row, and the same call with two pipelines (knob host_workers) gives the same bytes."""
+    import ctypes as C
+    from lz4net_amd import _lib
+    n = 5203
+    raw = oracle.gen(2, 4242, 0, n)
+    lens = np.full(n, 65536, np.int32)
+    lens[[0, 1, 2, 1733, 1734, 1735, 3467, 3468, n - 1]] = [0, 13, 65535, 12, 300, 65536, 4096, 1, 777]
+    cap = 65536 + 65536 // 255 + 16
+    caps = np.full(n, cap, np.int32)
+    outs = []
+    for workers in (0, 2):
+        dst = np.full((n, cap + 48), 0xA5, np.uint8)
+        res = np.full(n, -7, np.int32)
+        b = _lib.Batch(src=raw.ctypes.data, src_off=None, src_stride=raw.strides[0], src_len=lens.ctypes.data, dst=dst.ctypes.data, dst_off=None,
+                       dst_stride=dst.strides[0], dst_cap=caps.ctypes.data, dst_cap_all=0, src_len_all=65536, result=res.ctypes.data, n_blocks=n)
+        with _lib.tuning(host_workers=workers):
+            _lib.check(_lib.lib().lz4hip_encode_batch_host(C.byref(b), 0))
+        assert (dst[:, cap:] == 0xA5).all(), workers
+        outs.append((res, dst))
+    res, dst = outs[0]
+    assert np.array_equal(res, outs[1][0])
+    for i in range(n):
+        assert np.array_equal(dst[i, :res[i]], outs[1][1][i, :res[i]]), i
+    for i in [0, 1, 2, 3, 1732, 1733, 1734, 1735, 1736, 3466, 3467, 3468, 3469, n - 2, n - 1] + list(range(7, n, 211)):
+        ret, out = oracle.compress_raw(raw[i, :lens[i]], cap)
+        assert res[i] == ret, (i, res[i], ret)
+        assert bytes(dst[i, :ret]) == bytes(out[:ret]), i
+
+
 def test_host_entry_points_from_several_threads(gpu, oracle):
     """The host-pointer entry points keep their staging (pinned buffers, copy streams, events) per calling thread and
     share only the leased device workspaces: four threads encoding and decoding their own batches at the same time
