@@ -59,8 +59,8 @@ for r in range(rounds):
                     row[dstp:dstp + ln] = row[src:src + ln]
         blocks.append(row)
     want = [o.compress(a) for a in blocks]
-    for mapping in ("wave", "lane"):
-        with _lib.tuning(encoder=mapping):
+    for mapping, wg5 in (("wave", 1), ("wave", 2), ("lane", 0)):      # one block per workgroup, five per workgroup (launch_encode's form where that saves a residency round), lane per block
+        with _lib.tuning(encoder=mapping, encoder_wg5=wg5):
             for delta in (None, 0, -1, -5):
                 caps = None if delta is None else [max(len(w) + delta, 0) for w in want]
                 res, dst = gpu.encode(blocks, caps=caps)
@@ -72,7 +72,7 @@ for r in range(rounds):
                     if not ok:
                         bad += 1
                         if bad < 8:
-                            print("MISMATCH seed", seed, "round", r, "block", i, "size", a.size, mapping, delta, res[i], exp, flush=True)
+                            print("MISMATCH seed", seed, "round", r, "block", i, "size", a.size, mapping, wg5, delta, res[i], exp, flush=True)
                             np.save(f"/tmp/enc_fuzz_bad_{seed}_{r}_{i}.npy", a)
     print("round %d done: %d comparisons so far, %d mismatches, %.0f s" % (r, total, bad, time.time() - t0), flush=True)
 print("TOTAL %d comparisons, %d mismatches" % (total, bad))
