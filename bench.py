@@ -517,6 +517,7 @@ def main():
             clen_s = batch.encode(raw_s, batch.BLOCK, comp_s, batch.BOUND)
             back_s = torch.empty_like(raw_s)
             last_m = 0
+            comp_h = None
             for m in (1024, 4096, 16384, 65536, 262144):
                 if m > m_max:
                     continue
@@ -528,10 +529,16 @@ def main():
                 if m <= 65536:
                     t_enc = min(event_ms(lambda: batch.encode(raw_s[:m], batch.BLOCK, comp_s[:m], batch.BOUND), torch) for _ in range(2))
                     entry["encode_fast_GBps"] = round(m * batch.BLOCK / (t_enc / 1e3) / 1e9, 2)
+                    if comp_h is None:
+                        comp_h = torch.empty((min(65536, m_max), batch.BOUND_STRIDE), dtype=torch.uint8, device="cuda")
+                    batch.encode(raw_s[:m], batch.BLOCK, comp_h[:m], batch.BOUND, hc=True)      # (untimed: workspace, first launch)
+                    torch.cuda.synchronize()
+                    t_hc = event_ms(lambda: batch.encode(raw_s[:m], batch.BLOCK, comp_h[:m], batch.BOUND, hc=True), torch)
+                    entry["encode_hc_GBps"] = round(m * batch.BLOCK / (t_hc / 1e3) / 1e9, 2)
                 sweep[str(m)] = entry
             sweep["ok"] = last_m > 0 and batch.count_mismatches(raw_s[:last_m], back_s[:last_m], batch.BLOCK) == 0
             extras["batch_size_sweep_" + DIST_NAMES[args.dist].split("(")[0]] = sweep
-            del raw_s, comp_s, back_s
+            del raw_s, comp_s, back_s, comp_h
             # ---- the wavefront-mapped fast encoder on its own (what every batch below 49 152 blocks and every host-pointer slice runs; second
             #      version since round 6): 65 536 blocks of both sequence-dense distributions, forced mapping, EVERY block against the CPU reference ----
             wave_enc = {}
